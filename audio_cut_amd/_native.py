@@ -1,0 +1,272 @@
+"""ctypes binding of libaudiocut_hip.so (include/audiocut_hip.h) over PyTorch-owned device memory.
+
+PyTorch is plumbing here: it allocates HBM, owns the HIP stream and moves host arrays; every
+per-sample computation of the hot path happens in the HIP kernels behind these wrappers.  There is
+no CPU fallback: a missing library or a failing call raises `NativeError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+_LIB_NAME = "libaudiocut_hip.so"
+_lib: Optional[C.CDLL] = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def library_path() -> Path:
+    return Path(__file__).resolve().parent / _LIB_NAME
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (built in-tree by `__graft_entry__.build()` / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise NativeError(f"{path} is missing: build it with `make -C audio_cut_amd/csrc` "
+                          f"(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(str(path))
+    _declare(lib)
+    if lib.ac_abi_version() != 1:
+        raise NativeError("libaudiocut_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I = C.c_int
+
+SIGNATURES = {
+    "ac_abi_version": (C.c_int, []),
+    "ac_last_error": (C.c_char_p, []),
+    "ac_ctx_create": (C.c_int, [_I, C.POINTER(_P)]),
+    "ac_ctx_destroy": (C.c_int, [_P]),
+    "ac_frame_rms": (C.c_int, [_P, _P, _I64, _I, _I, _I, _P, _I64, _P]),
+    "ac_stft2048_features": (C.c_int, [_P, _P, _I64, _I, _P, _P, _P, _P, _P, _I64, _P]),
+    "ac_onset_strength": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P]),
+    "ac_tempogram_parts": (C.c_int, [_I64]),
+    "ac_tempogram_reduce": (C.c_int, [_P, _P, _I64, _I, _P, _P, _P, _P, _P]),
+    "ac_moving_meansq_db_f64": (C.c_int, [_P, _P, _I64, _I, _P, _P]),
+    "ac_next_leq_scratch": (C.c_int64, [_I64]),
+    "ac_next_leq_scan": (C.c_int, [_P, _P, _I64, C.c_double, _P, _P, _P]),
+    "ac_window_argmin_f64": (C.c_int, [_P, _P, _I64, _P, _P, _I, _P, _P, _P]),
+    "ac_zero_cross_nearest": (C.c_int, [_P, _P, _I64, _P, _I, _I, _P, _P]),
+    "ac_quiet_guard_slow": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P]),
+    "ac_pause_cut_points": (C.c_int, [_P, _P, _I64, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "ac_mdx_stft": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _P, _P]),
+    "ac_mdx_istft": (C.c_int, [_P, _P, _I, _P, _P, _P]),
+    "ac_mdx_assemble_ola": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
+}
+
+
+def _declare(lib: C.CDLL) -> None:
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = load().ac_last_error()
+        raise NativeError(f"libaudiocut_hip call failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise NativeError("non-contiguous tensor passed to the HIP ABI")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Context:
+    """Per-device handle (ac_ctx) + thin typed wrappers; tensors must live on this device."""
+
+    def __init__(self, device: str = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise NativeError("no HIP device visible to PyTorch: the audio-cut HIP path needs a GPU")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise NativeError(f"device {device!r} is not a HIP device")
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self.index)
+        self.lib = load()
+        handle = _P()
+        with torch.cuda.device(self.index):
+            _check(self.lib.ac_ctx_create(self.index, C.byref(handle)))
+        self._h = handle
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.ac_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def to_device(self, arr, dtype=None) -> torch.Tensor:
+        t = torch.as_tensor(np.ascontiguousarray(arr))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device, non_blocking=False).contiguous()
+
+    def _chk_f32(self, x: torch.Tensor) -> None:
+        if x.dtype != torch.float32 or x.device != self.device or x.dim() != 1:
+            raise NativeError("expected a 1-D float32 tensor on the context's device")
+
+    # -- framewise ---------------------------------------------------------------------------------
+    def frame_rms(self, x: torch.Tensor, frame: int, hop: int, center: bool = True) -> torch.Tensor:
+        self._chk_f32(x)
+        n = x.numel()
+        pad = frame // 2 if center else 0
+        if n + 2 * pad < frame:
+            raise NativeError("signal shorter than one frame")
+        nf = 1 + (n + 2 * pad - frame) // hop
+        out = torch.empty(nf, dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_frame_rms(self._h, _ptr(x), n, frame, hop, int(center), _ptr(out), nf, _stream()))
+        return out
+
+    def stft2048_features(self, x: torch.Tensor, hop: int, *, want_flat: bool = True, want_mel: bool = False,
+                          frame_center: Optional[torch.Tensor] = None, frame_lo: Optional[torch.Tensor] = None,
+                          frame_hi: Optional[torch.Tensor] = None):
+        self._chk_f32(x)
+        n = x.numel()
+        nf = frame_center.numel() if frame_center is not None else 1 + n // hop
+        flat = torch.empty(nf, dtype=torch.float32, device=self.device) if want_flat else None
+        mel = torch.empty((nf, 128), dtype=torch.float32, device=self.device) if want_mel else None
+        _check(self.lib.ac_stft2048_features(self._h, _ptr(x), n, hop, _ptr(frame_center), _ptr(frame_lo), _ptr(frame_hi),
+                                             _ptr(flat), _ptr(mel), nf, _stream()))
+        return flat, mel
+
+    def onset_strength(self, mel: torch.Tensor, hop: int, aggregate: str = "mean",
+                       group_start: Optional[Sequence[int]] = None) -> torch.Tensor:
+        nf = mel.shape[0]
+        gs = [0, nf] if group_start is None else list(group_start)
+        gs_t = self.to_device(np.asarray(gs, dtype=np.int64))
+        env = torch.empty(nf, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(len(gs) - 1, dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_onset_strength(self._h, _ptr(mel), nf, _ptr(gs_t), len(gs) - 1, hop,
+                                          0 if aggregate == "mean" else 1, _ptr(env), _ptr(scratch), _stream()))
+        return env
+
+    def tempogram_reduce(self, env: torch.Tensor, win: int, logprior: np.ndarray, want_argmax: bool = True):
+        self._chk_f32(env)
+        n = env.numel()
+        parts = self.lib.ac_tempogram_parts(n)
+        lp = self.to_device(np.asarray(logprior, dtype=np.float64))
+        mean = torch.empty(win, dtype=torch.float64, device=self.device)
+        arg = torch.empty(n, dtype=torch.int32, device=self.device) if want_argmax else None
+        scratch = torch.empty(parts * win, dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_tempogram_reduce(self._h, _ptr(env), n, win, _ptr(lp), _ptr(mean), _ptr(arg), _ptr(scratch), _stream()))
+        return mean, arg
+
+    # -- guard ---------------------------------------------------------------------------------------
+    def moving_meansq_db(self, x: torch.Tensor, win: int) -> torch.Tensor:
+        self._chk_f32(x)
+        out = torch.empty(x.numel(), dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_moving_meansq_db_f64(self._h, _ptr(x), x.numel(), win, _ptr(out), _stream()))
+        return out
+
+    def next_leq_scan(self, db: torch.Tensor, floor_db: float) -> torch.Tensor:
+        n = db.numel()
+        out = torch.empty(n, dtype=torch.int64, device=self.device)
+        scratch = torch.empty(int(self.lib.ac_next_leq_scratch(n)), dtype=torch.int64, device=self.device)
+        _check(self.lib.ac_next_leq_scan(self._h, _ptr(db), n, float(floor_db), _ptr(out), _ptr(scratch), _stream()))
+        return out
+
+    def window_argmin(self, db: torch.Tensor, start: np.ndarray, length: np.ndarray):
+        k = len(start)
+        s = self.to_device(np.asarray(start, dtype=np.int64)); ln = self.to_device(np.asarray(length, dtype=np.int64))
+        arg = torch.empty(k, dtype=torch.int64, device=self.device)
+        val = torch.empty((k, 2), dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_window_argmin_f64(self._h, _ptr(db), db.numel(), _ptr(s), _ptr(ln), k, _ptr(arg), _ptr(val), _stream()))
+        return arg.cpu().numpy(), val.cpu().numpy()
+
+    def zero_cross_nearest(self, x: torch.Tensor, idx: np.ndarray, half: int) -> np.ndarray:
+        self._chk_f32(x)
+        k = len(idx)
+        i = self.to_device(np.asarray(idx, dtype=np.int64))
+        pos = torch.empty(k, dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_zero_cross_nearest(self._h, _ptr(x), x.numel(), _ptr(i), int(half), k, _ptr(pos), _stream()))
+        return pos.cpu().numpy()
+
+    def quiet_guard_slow(self, x: torch.Tensor, idx: np.ndarray, span: int, win: int):
+        self._chk_f32(x)
+        k = len(idx)
+        i = self.to_device(np.asarray(idx, dtype=np.int64))
+        arg = torch.empty(k, dtype=torch.int64, device=self.device)
+        val = torch.empty((k, 2), dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_quiet_guard_slow(self._h, _ptr(x), x.numel(), _ptr(i), int(span), int(win), k, _ptr(arg), _ptr(val), _stream()))
+        return arg.cpu().numpy(), val.cpu().numpy()
+
+    def pause_cut_points(self, x: torch.Tensor, a: np.ndarray, b: np.ndarray, win: int, guard: int):
+        self._chk_f32(x)
+        k = len(a)
+        ta = self.to_device(np.asarray(a, dtype=np.int64)); tb = self.to_device(np.asarray(b, dtype=np.int64))
+        cut = torch.empty(k, dtype=torch.int64, device=self.device)
+        aux = torch.empty((k, 2), dtype=torch.int64, device=self.device)
+        _check(self.lib.ac_pause_cut_points(self._h, _ptr(x), x.numel(), _ptr(ta), _ptr(tb), k, int(win), int(guard),
+                                            _ptr(cut), _ptr(aux), _stream()))
+        return cut.cpu().numpy(), aux.cpu().numpy()
+
+    # -- MDX23 ---------------------------------------------------------------------------------------
+    def mdx_stft(self, track: torch.Tensor, chunk_start: torch.Tensor, chunk_len: torch.Tensor,
+                 win_index: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._chk_f32(track)
+        n_items = chunk_start.numel()
+        if out is None:
+            out = torch.empty((n_items, 4, 256, 3072), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_mdx_stft(self._h, _ptr(track), track.numel(), _ptr(chunk_start), _ptr(chunk_len), _ptr(win_index),
+                                    n_items, _ptr(out), _stream()))
+        return out
+
+    def mdx_istft(self, spec: torch.Tensor) -> torch.Tensor:
+        if spec.dtype != torch.float32 or tuple(spec.shape[1:]) != (4, 256, 3072):
+            raise NativeError("mdx_istft expects float32 [items, 4, 256, 3072]")
+        n_items = spec.shape[0]
+        wave = torch.empty((n_items, 2, 261120), dtype=torch.float32, device=self.device)
+        scratch = torch.empty((n_items * 2 * 256 * 6144,), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_mdx_istft(self._h, _ptr(spec), n_items, _ptr(wave), _ptr(scratch), _stream()))
+        return wave
+
+    def mdx_assemble_ola(self, track: torch.Tensor, wave: torch.Tensor, chunk_start, chunk_len, eff_start, eff_end, item_base):
+        self._chk_f32(track)
+        n = track.numel()
+        vocal = torch.empty(n, dtype=torch.float32, device=self.device)
+        inst = torch.empty(n, dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_mdx_assemble_ola(self._h, _ptr(track), n, _ptr(wave), _ptr(chunk_start), _ptr(chunk_len),
+                                            _ptr(eff_start), _ptr(eff_end), _ptr(item_base), chunk_start.numel(),
+                                            _ptr(vocal), _ptr(inst), _stream()))
+        return vocal, inst
+
+
+def host_beat_dp(localscore: np.ndarray, period: float, tightness: float):
+    """librosa's beat-tracking DP, sequential, in C++ on the host (ac_host_beat_dp)."""
+    lib = load()
+    ls = np.ascontiguousarray(localscore, dtype=np.float64)
+    n = ls.size
+    back = np.empty(n, dtype=np.int64)
+    cum = np.zeros(n, dtype=np.float64)
+    _check(lib.ac_host_beat_dp(ls.ctypes.data, n, float(period), float(tightness), back.ctypes.data, cum.ctypes.data))
+    return back, cum

@@ -1,0 +1,75 @@
+// Shared declarations for libaudiocut_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/audiocut_hip.h"
+
+#define AC_WAVE 64
+
+struct ac_ctx {
+    int device;
+    // real-FFT 2048 (float64): tw2048[k] = exp(-2*pi*i*k/2048), k < 1024 ; hann2048 periodic (float64)
+    double2* tw2048;
+    double* hann2048;
+    // mel filter bank (128 x 1025 float32, Slaney) as dense rows + [lo, hi) non-zero ranges
+    float* mel_w;
+    int* mel_lo;
+    int* mel_hi;
+    // real-FFT 6144 (float32): tw6144[k] = exp(-2*pi*i*k/6144), k < 3072 ; hann6144 periodic (float32)
+    float2* tw6144;
+    float* hann6144;
+    float* ola_env6144;  // 1 / sum_t w^2 over the 256-frame lattice, length 267264 (padded coordinates)
+};
+
+void ac_set_error(const char* fmt, ...);
+
+#define AC_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ac_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AC_E_HIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+#define AC_REQUIRE(cond, msg)                                   \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            ac_set_error("invalid argument: %s (%s)", msg, #cond); \
+            return AC_E_INVALID;                                \
+        }                                                       \
+    } while (0)
+
+#define AC_LAUNCH_CHECK()                                                       \
+    do {                                                                        \
+        hipError_t _e = hipGetLastError();                                      \
+        if (_e != hipSuccess) {                                                 \
+            ac_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AC_E_HIP;                                                    \
+        }                                                                       \
+    } while (0)
+
+// ---- wave / block reductions (64-wide) -------------------------------------------------------
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, AC_WAVE);
+    return v;
+}
+__device__ inline float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, AC_WAVE));
+    return v;
+}
+
+// Block-wide sum of doubles for blockDim.x == 256 (4 waves); result valid in every thread.
+__device__ inline double block_sum_f64_256(double v, double* smem4) {
+    v = wave_sum_f64(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem4[w] = v;
+    __syncthreads();
+    return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}

@@ -1,0 +1,154 @@
+/*
+ * audiocut_hip.h — C ABI of libaudiocut_hip.so: the MI355X (gfx950) kernels under the audio-cut
+ * separate+detect hot path.  Loaded from Python with ctypes
+ * (audio_cut_amd/_native.py); see INTEGRATION.md for the stub a maintainer of the reference adds.
+ *
+ * The reference (BDMstudio/audio-cut) has no FFI: the path is Python calling librosa / torch /
+ * onnxruntime.  Every entry point below therefore cites the reference *call site* whose per-sample
+ * arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd by the caller; PyTorch owns the memory in the
+ *     Python host) unless the name ends in _h; sizes are element counts;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on
+ *     that stream and never synchronise, allocate or free device memory (graph-capture safe);
+ *   - return value 0 = ok, negative = error (AC_E_*); text via ac_last_error() (thread-local);
+ *   - no exceptions cross the ABI, no global state besides the per-device context handle.
+ */
+#ifndef AUDIOCUT_HIP_H
+#define AUDIOCUT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_OK 0
+#define AC_E_INVALID (-1)   /* bad argument (shape/size the kernels do not support) */
+#define AC_E_HIP (-2)       /* a HIP runtime call failed */
+#define AC_E_NOMEM (-3)
+
+#define AC_ABI_VERSION 1
+
+typedef struct ac_ctx ac_ctx;
+
+int ac_abi_version(void);
+const char* ac_last_error(void);
+
+/* Per-device context: twiddle / window / mel tables resident in HBM.  (new; no reference analogue) */
+int ac_ctx_create(int device, ac_ctx** out);
+int ac_ctx_destroy(ac_ctx* ctx);
+
+/* ---- framewise features ------------------------------------------------------------------- */
+
+/* librosa.feature.rms(y, frame_length, hop_length, center=True, pad_mode="constant")
+ * call sites: analysis/features_cache.py:182 (4410/2205), core/pure_vocal_pause_detector.py:1113
+ * (1102/441), :1397 (2048/441), core/seamless_splitter.py:1714,1848 (2048/441),
+ * core/vocal_separator.py:483 (2205/882).  out[n_frames] f32, n_frames = 1 + (n + 2*(frame/2) - frame)/hop
+ * when center, else 1 + (n - frame)/hop. */
+int ac_frame_rms(ac_ctx* ctx, const float* x, int64_t n, int frame, int hop, int center,
+                 float* out, int64_t n_frames, void* stream);
+
+/* STFT(n_fft=2048, periodic Hann, center, zero pad) -> |X|^2 -> spectral flatness and/or mel-128
+ * power, one pass.  Replaces librosa.feature.spectral_flatness (features_cache.py:183,
+ * pure_vocal_pause_detector.py:1117) and the melspectrogram inside librosa.onset.onset_strength
+ * (features_cache.py:184, adaptive_vad_enhancer.py:143).  Frame f is centred on sample
+ * frame_center[f] (NULL: f*hop) and sees zeros outside [frame_lo[f], frame_hi[f]) (NULL: [0, n)) —
+ * that is how the per-chunk calls of features_cache.py:181-187 (chunk-local zero padding) are
+ * evaluated for all chunks of a track in one launch.
+ * flat_out[n_frames] f32 (may be NULL), mel_out[n_frames*128] f32 frame-major (may be NULL). */
+int ac_stft2048_features(ac_ctx* ctx, const float* x, int64_t n, int hop, const int64_t* frame_center,
+                         const int64_t* frame_lo, const int64_t* frame_hi, float* flat_out,
+                         float* mel_out, int64_t n_frames, void* stream);
+
+/* power_to_db(top_db=80) + lag-1 positive difference + aggregate over 128 mels
+ * (librosa.onset.onset_strength: aggregate 0 = mean (features_cache.py:184), 1 = median
+ * (adaptive_vad_enhancer.py:143-148)).  mel is processed in `n_groups` independent frame groups
+ * (group g = frames [group_start[g], group_start[g+1])) each with its own top_db reference, which is
+ * how the per-chunk calls of features_cache.py:181-187 clip.  env_out[n_frames] f32 with the
+ * librosa left padding (lag + 1024/hop) applied inside every group.  scratch: n_groups floats. */
+int ac_onset_strength(ac_ctx* ctx, const float* mel, int64_t n_frames, const int64_t* group_start,
+                      int n_groups, int hop, int aggregate, float* env_out, float* scratch, void* stream);
+
+/* librosa.feature.tempogram(win_length, center, hann, norm=inf) reduced on the fly:
+ * mean_out[win] f64 = mean over frames of the normalised autocorrelation (what tempo(aggregate=mean)
+ * consumes: adaptive_vad_enhancer.py:61 via beat_track, features_cache.py:289), and
+ * argmax_out[n] i32 = argmax_lag(log1p(1e6*tg) + logprior) per frame (tempo(aggregate=None):
+ * adaptive_vad_enhancer.py:151, features_cache.py:283).  logprior[win] f64 is supplied by the host.
+ * scratch: n_parts*win doubles, n_parts = ac_tempogram_parts(n). */
+int ac_tempogram_parts(int64_t n);
+int ac_tempogram_reduce(ac_ctx* ctx, const float* env, int64_t n, int win, const double* logprior,
+                        double* mean_out, int32_t* argmax_out, double* scratch, void* stream);
+
+/* ---- quiet guard / cut refinement --------------------------------------------------------- */
+
+/* cutting/refine.py:170-174: float64 moving mean of x^2 (np.convolve(...,'same'), window `win`)
+ * -> 20*log10(sqrt(ms + 1e-12) + 1e-12).  db_out[n] f64. */
+int ac_moving_meansq_db_f64(ac_ctx* ctx, const float* x, int64_t n, int win, double* db_out, void* stream);
+
+/* cutting/refine.py:175-180: next_out[i] = smallest j >= i with db[j] <= floor_db, else -1.
+ * scratch: ac_next_leq_scratch(n) int64 elements. */
+int64_t ac_next_leq_scratch(int64_t n);
+int ac_next_leq_scan(ac_ctx* ctx, const double* db, int64_t n, double floor_db, int64_t* next_out,
+                     int64_t* scratch, void* stream);
+
+/* cutting/refine.py:203-207: first argmin of db[start[q] : start[q]+len[q]) for k windows.
+ * arg_out[k] i64 (absolute index), val_out[2k] f64 = (db[start], db[argmin]). */
+int ac_window_argmin_f64(ac_ctx* ctx, const double* db, int64_t n, const int64_t* start,
+                         const int64_t* len, int k, int64_t* arg_out, double* val_out, void* stream);
+
+/* cutting/refine.py:72-110: nearest (fractional) zero crossing to idx[q] within +-half[q] samples;
+ * pos_out[k] f64 (NaN = none).  Scalar promotion follows numpy<2 (float64), see DESIGN.md. */
+int ac_zero_cross_nearest(ac_ctx* ctx, const float* x, int64_t n, const int64_t* idx, int half,
+                          int k, double* pos_out, void* stream);
+
+/* cutting/refine.py:113-157 (slow guard): edge-padded `win`-sample RMS over x[idx : idx+span),
+ * 'valid' window sums, dB, first argmin.  arg_out[k] i64 = offset of the minimum (or -1 when the
+ * reference returns early), val_out[2k] f64 = (db[0], db[argmin]). */
+int ac_quiet_guard_slow(ac_ctx* ctx, const float* x, int64_t n, const int64_t* idx, int span, int win,
+                        int k, int64_t* arg_out, double* val_out, void* stream);
+
+/* core/pure_vocal_pause_detector.py:1047-1078: per pause, segment-local 'same' moving RMS (float32
+ * semantics, window `win`) argmin over x[a:b), then the look-ahead argmin over x[cut : cut+guard);
+ * cut_out[k] i64 = sample index after the look-ahead; aux_out[2k] i64 = (zeros in |x[a:b)|, 1 if
+ * x[cut] != 0 else 0) for the silence-floor test at :1080-1083. */
+int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const int64_t* a, const int64_t* b,
+                        int k, int win, int guard, int64_t* cut_out, int64_t* aux_out, void* stream);
+
+/* ---- MDX23 separator front/back end -------------------------------------------------------- */
+
+/* separation/backends.py:306-330 (windowing) + external Conv_TDF_net_trim_model.stft (:355):
+ * for item q = (chunk_start[q], chunk_len[q], win_index[q]) build the 261120-sample window with
+ * 3072-sample zero margins straight from the resident mono track, reflect-pad, Hann(6144) STFT,
+ * hop 1024, keep bins 0..3071.  spec_out[n_items][4][256][3072] f32 (T-major: the U-Net's internal
+ * layout; channels L.re, L.im, R.re, R.im of the mono-duplicated input, backends.py:269-270). */
+int ac_mdx_stft(ac_ctx* ctx, const float* track, int64_t n, const int64_t* chunk_start,
+                const int64_t* chunk_len, const int32_t* win_index, int n_items, float* spec_out,
+                void* stream);
+
+/* external Conv_TDF_net_trim_model.istft (backends.py:376): spec[n_items][4][256][3072] ->
+ * wave_out[n_items][2][261120] f32 (zero top bin, inverse FFT, Hann, overlap-add / window envelope).
+ * scratch: n_items*2*256*6144 floats. */
+int ac_mdx_istft(ac_ctx* ctx, const float* spec, int n_items, float* wave_out, float* scratch, void* stream);
+
+/* backends.py:377,389-406 + core/enhanced_vocal_separator.py:423-437,456-458: trim the 3072 margins,
+ * place the windows, crop, instrumental = mix - vocal, channel mean, then uniform overlap-add of the
+ * effective regions of all chunks.  chunk tables: start/len (samples), eff_start/eff_end (absolute),
+ * item_base[c] = first item of chunk c.  vocal_out[n], inst_out[n] f32. */
+int ac_mdx_assemble_ola(ac_ctx* ctx, const float* track, int64_t n, const float* wave,
+                        const int64_t* chunk_start, const int64_t* chunk_len, const int64_t* eff_start,
+                        const int64_t* eff_end, const int32_t* item_base, int n_chunks,
+                        float* vocal_out, float* inst_out, void* stream);
+
+/* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
+
+/* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score
+ * (adaptive_vad_enhancer.py:61, features_cache.py:289).  backlink_h[n] i64, cumscore_h[n] f64. */
+int ac_host_beat_dp(const double* localscore_h, int64_t n, double period, double tightness,
+                    int64_t* backlink_h, double* cumscore_h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOCUT_HIP_H */
