@@ -67,6 +67,8 @@ SIGNATURES = {
     "ac_mdx_stft": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _P, _P]),
     "ac_mdx_istft": (C.c_int, [_P, _P, _I, _P, _P, _P]),
     "ac_mdx_assemble_ola": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "ac_mdx_chunk_vocal": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P]),
+    "ac_sum_squares": (C.c_int, [_P, _P, _I64, _P, _I, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -259,6 +261,24 @@ class Context:
                                             _ptr(eff_start), _ptr(eff_end), _ptr(item_base), chunk_start.numel(),
                                             _ptr(vocal), _ptr(inst), _stream()))
         return vocal, inst
+
+
+    def mdx_chunk_vocal(self, wave: torch.Tensor, chunk_len: torch.Tensor, out_offset: torch.Tensor, item_base: torch.Tensor,
+                        total: int) -> torch.Tensor:
+        out = torch.empty(int(total), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_mdx_chunk_vocal(self._h, _ptr(wave), _ptr(chunk_len), _ptr(out_offset), _ptr(item_base),
+                                           chunk_len.numel(), _ptr(out), _stream()))
+        return out
+
+    def mean_square(self, x: torch.Tensor) -> float:
+        self._chk_f32(x)
+        n = x.numel()
+        if n == 0:
+            return 0.0
+        parts = min(1024, max(1, n // 4096))
+        buf = torch.empty(parts, dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_sum_squares(self._h, _ptr(x), n, _ptr(buf), parts, _stream()))
+        return float(np.sum(buf.cpu().numpy())) / float(n)
 
 
 def host_beat_dp(localscore: np.ndarray, period: float, tightness: float):

@@ -241,3 +241,51 @@ extern "C" int ac_mdx_assemble_ola(ac_ctx* ctx, const float* track, int64_t n, c
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Per-chunk mono vocal (what `backend.infer_chunk(...).vocal` is in the reference, backends.py:389-406):
+// the chunked VAD consumes it before the overlap-add (enhanced_vocal_separator.py:412-417).
+// out is the concatenation of all chunks' vocals; out_offset[c] = first element of chunk c.
+__global__ __launch_bounds__(256) void k_mdx_chunk_vocal(const float* __restrict__ wave, const int64_t* __restrict__ chunk_len,
+                                                         const int64_t* __restrict__ out_offset,
+                                                         const int32_t* __restrict__ item_base, float* __restrict__ out) {
+    const int c = blockIdx.y;
+    const int64_t cl = chunk_len[c];
+    float* dst = out + out_offset[c];
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < cl; q += (int64_t)gridDim.x * 256) {
+        const int item = item_base[c] + (int)(q / MDX_GEN);
+        const int pos = MDX_TRIM + (int)(q % MDX_GEN);
+        const float w0 = wave[((size_t)item * 2 + 0) * MDX_ITEM + pos];
+        const float w1 = wave[((size_t)item * 2 + 1) * MDX_ITEM + pos];
+        dst[q] = (w0 + w1) * 0.5f;
+    }
+}
+
+extern "C" int ac_mdx_chunk_vocal(ac_ctx* ctx, const float* wave, const int64_t* chunk_len, const int64_t* out_offset,
+                                  const int32_t* item_base, int n_chunks, float* out, void* stream) {
+    AC_REQUIRE(ctx && wave && chunk_len && out_offset && item_base && out, "null pointer");
+    AC_REQUIRE(n_chunks > 0 && n_chunks <= 65535, "n_chunks must be in [1, 65535]");
+    hipLaunchKernelGGL(k_mdx_chunk_vocal, dim3(256, n_chunks), dim3(256), 0, (hipStream_t)stream, wave, chunk_len, out_offset,
+                       item_base, out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-block partial sums of squares in float64 (enhanced_vocal_separator.py:490-501 energy ratios);
+// the host adds the (<= 4096) partials in index order, so the result is deterministic.
+__global__ __launch_bounds__(256) void k_sum_squares(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = x[i]; acc += v * v; }
+    const double tot = block_sum_f64_256(acc, s_red);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+extern "C" int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int n_partials, void* stream) {
+    AC_REQUIRE(ctx && x && partials, "null pointer");
+    AC_REQUIRE(n > 0 && n_partials > 0 && n_partials <= 4096, "n_partials must be in [1, 4096]");
+    hipLaunchKernelGGL(k_sum_squares, dim3(n_partials), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

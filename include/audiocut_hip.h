@@ -141,6 +141,14 @@ int ac_mdx_assemble_ola(ac_ctx* ctx, const float* track, int64_t n, const float*
                         const int64_t* eff_end, const int32_t* item_base, int n_chunks,
                         float* vocal_out, float* inst_out, void* stream);
 
+/* backends.py:389-406 per chunk: the mono vocal of every chunk before the overlap-add (the chunked VAD
+ * input, enhanced_vocal_separator.py:412-417).  out = concatenation, chunk c at out_offset[c]. */
+int ac_mdx_chunk_vocal(ac_ctx* ctx, const float* wave, const int64_t* chunk_len, const int64_t* out_offset,
+                       const int32_t* item_base, int n_chunks, float* out, void* stream);
+
+/* enhanced_vocal_separator.py:490-501: float64 partial sums of x^2 (n_partials blocks, summed by the host). */
+int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int n_partials, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score

@@ -81,11 +81,18 @@ def detect_and_finalize(mix: np.ndarray, vocal: np.ndarray, sr: int, cache: Opti
             for a, b in D.no_vocal_runs(vocal, sr, min_music):
                 cands.append((float(a), 1.0)); cands.append((float(b), 1.0))
         dur = len(mix) / sr
+        protected = set()
         for t in (markers or {}).get("vocal_presence_cut_points_sec", []):
             if 0.0 < t < dur:
                 cands.append((float(t), 1.0))
+                protected.add(int(round(t * sr)))
         refined = finalize_and_filter_cuts(cands, mix, vocal, sr)
-        bounds = sorted(set(refined.sample_boundaries))
+        bounds = set(refined.sample_boundaries)
+        for s in protected:                      # seamless_splitter.py:501-508
+            s = int(min(max(s, 0), len(mix)))
+            if s not in (0, len(mix)):
+                bounds.add(s)
+        bounds = sorted(bounds)
     else:   # seamless_splitter.py:421-433: no candidates -> single segment
         bounds = [0, len(mix)]
     t2 = time.perf_counter()
