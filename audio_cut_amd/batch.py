@@ -1,0 +1,51 @@
+"""Track-sharded batches across the GPUs of one node.
+
+Tracks are independent units (the reference processes one file per call, `src/audio_cut/api.py:102-109`,
+and its only multi-device tool loops devices sequentially, `scripts/bench/run_multi_gpu_probe.py:107`).
+One process per GPU; tracks are dealt longest-processing-time-first; there is NO data-path
+collective — the only communication is batch completion: a barrier and one `all_gather_object` of
+per-track summaries (a few hundred bytes each; over RCCL/xGMI on the GPU box, over gloo in the CPU
+tests).
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+def assign_tracks(durations_s: Sequence[float], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first: returns, per rank, the indices of its tracks (stable for ties)."""
+    world_size = max(1, int(world_size))
+    order = sorted(range(len(durations_s)), key=lambda i: (-float(durations_s[i]), i))
+    loads = [0.0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += float(durations_s[i])
+    for r in range(world_size):
+        out[r].sort()
+    return out
+
+
+def summarize(track_index: int, sample_boundaries: Sequence[int], seconds: float, timings: Optional[Dict[str, float]] = None) -> Dict:
+    b = np.asarray(list(sample_boundaries), dtype=np.int64)
+    return {"track": int(track_index), "n_boundaries": int(b.size), "boundaries_sha1": hashlib.sha1(b.tobytes()).hexdigest(),
+            "audio_seconds": float(seconds), "timings": dict(timings or {})}
+
+
+def gather_summaries(local: List[Dict], group=None) -> List[Dict]:
+    """Batch completion: barrier + all_gather_object; every rank returns the full, track-ordered list."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sorted(local, key=lambda d: d["track"])
+    dist.barrier(group=group)
+    buckets: List[Optional[List[Dict]]] = [None] * dist.get_world_size(group)
+    dist.all_gather_object(buckets, local, group=group)
+    merged = [d for b in buckets for d in (b or [])]
+    return sorted(merged, key=lambda d: d["track"])
+
+
+__all__ = ["assign_tracks", "summarize", "gather_summaries"]

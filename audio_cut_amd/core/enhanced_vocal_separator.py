@@ -139,14 +139,16 @@ class EnhancedVocalSeparator:
         return ctx
 
     # ------------------------------------------------------------------------------------------
-    def separate_for_detection(self, audio: np.ndarray, *, gpu_context: Optional[PipelineContext] = None) -> SeparationResult:
+    def separate_for_detection(self, audio: np.ndarray, *, gpu_context: Optional[PipelineContext] = None,
+                               audio_dev: Optional[torch.Tensor] = None) -> SeparationResult:
+        """`audio_dev` (extension): the same mono track already resident in HBM; skips the upload."""
         backend = self._primary_backend
         if backend is None:
             raise RuntimeError("separator backend not initialised")
         start = time.time()
         ctx = self._ensure_pipeline_context(audio, gpu_context)
         try:
-            vocal, inst, cache, vad_segments, markers, confidence, state = self._separate_with_pipeline(audio, backend, ctx)
+            vocal, inst, cache, vad_segments, markers, confidence, state = self._separate_with_pipeline(audio, backend, ctx, audio_dev)
         except Exception as exc:
             ctx.mark_failure("separation", str(exc))
             raise
@@ -156,7 +158,8 @@ class EnhancedVocalSeparator:
             backend_used=type(backend).__name__, processing_time=time.time() - start, quality_metrics=markers,
             feature_cache=cache, vad_segments=vad_segments, gpu_meta=meta, pipeline_used=ctx.enabled, device_state=state)
 
-    def _separate_with_pipeline(self, audio: np.ndarray, backend: IVocalSeparatorBackend, gpu_context: PipelineContext):
+    def _separate_with_pipeline(self, audio: np.ndarray, backend: IVocalSeparatorBackend, gpu_context: PipelineContext,
+                                audio_dev: Optional[torch.Tensor] = None):
         if not isinstance(backend, MDX23HipBackend):
             raise RuntimeError("only MDX23HipBackend drives the batched device path")
         sr = self.sample_rate
@@ -167,7 +170,12 @@ class EnhancedVocalSeparator:
         torch.cuda.reset_peak_memory_stats(hip.device)
         backend.reset_performance_metrics()
         t0 = time.perf_counter()
-        mix_dev = hip.to_device(np.ascontiguousarray(audio, dtype=np.float32))
+        if audio_dev is not None:
+            if audio_dev.numel() != total or audio_dev.dtype != torch.float32:
+                raise ValueError("audio_dev must be the float32 device copy of `audio`")
+            mix_dev = audio_dev
+        else:
+            mix_dev = hip.to_device(np.ascontiguousarray(audio, dtype=np.float32))
         torch.cuda.synchronize(hip.device)
         h2d_ms = (time.perf_counter() - t0) * 1000.0
 

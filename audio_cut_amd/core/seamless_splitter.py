@@ -65,13 +65,13 @@ class SeamlessSplitter:
         return self._hip
 
     # ------------------------------------------------------------------------------------------
-    def split_track(self, original_audio: np.ndarray, mode: str = "v2.2_mdd") -> Dict:
+    def split_track(self, original_audio: np.ndarray, mode: str = "v2.2_mdd", *, audio_dev=None) -> Dict:
         """Steps 2-9 of SURVEY.md §3.1 on an in-memory mono float32 track at `sample_rate`."""
         if mode not in self.SUPPORTED_MODES:
             raise NotImplementedError(f"mode {mode!r}: only the v2.2_mdd / v2.1 path is built this round")
         sr = self.sample_rate
         t0 = time.perf_counter()
-        sep: SeparationResult = self.separator.separate_for_detection(original_audio, gpu_context=None)
+        sep: SeparationResult = self.separator.separate_for_detection(original_audio, gpu_context=None, audio_dev=audio_dev)
         t_sep = time.perf_counter() - t0
         state = sep.device_state or {}
         vocal_track = sep.vocal_track

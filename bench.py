@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds processed per wall-second (separate + detect) on MI355X.
+
+A "step" is one pass of the hot path over one synthetic track of the
+BASELINE.json configs[1] shape: 4-min 44.1 kHz song (stereo generator, mono down-mix as the reference's
+loader produces), chunked MDX23 separation (full-size TFC-TDF U-Net, seeded synthetic weights — the
+Kim_Vocal_1.onnx file cannot be fetched offline) + TrackFeatureCache + chunked VAD + pause detection +
+quiet-guard cut refinement.  The track is resident in HBM when the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: one process per GPU, every rank runs K tracks (weak scaling; tracks are independent, no data-path
+collective), batch completion = RCCL barrier + all_gather_object of per-track summaries.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+
+METRIC = "audio-seconds processed/sec (separate+detect) per GPU; cut-point index parity"
+F32_MATRIX_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_32x32x2_f32
+
+
+def cpu_baseline(sample_s: float, weights, spec) -> dict:
+    """The oracle (CPU restatement of the reference path: torch-CPU STFT/U-Net/iSTFT + numpy detection and
+    guard) timed on this host's cores on a bounded sample of the same workload."""
+    from audio_cut_amd.testing import signals
+    from oracle import e2e as OE, refine as OR
+    OR.LEGACY_PROMOTION = True
+    threads = int(os.environ.get("AC_CPU_BASELINE_THREADS", os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    mix = signals.c2_song(sample_s, seed=2)
+    t0 = time.perf_counter()
+    res = OE.run_track(mix, 44100, weights)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_s / dt, 4), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample_s:g} s of the C2 track generator (seed 2), full oracle path, one pass",
+            "seconds": round(dt, 2), "phases_s": {k: round(v, 3) for k, v in res.timings.items()},
+            "n_boundaries": len(res.sample_boundaries)}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--track-seconds", type=float, default=240.0)
+    ap.add_argument("--items-per-forward", type=int, default=16)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    from audio_cut_amd import _native, batch
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    from audio_cut_amd.testing import signals
+
+    sr = 44100
+    spec = TfcTdfSpec()
+    weights = synth_weights(spec, seed=0)
+    hip = _native.Context(device)
+    backend = MDX23HipBackend(weights=weights, ctx=hip, max_items_per_forward=args.items_per_forward)
+    backend.load_model()
+    splitter = SeamlessSplitter(sr, separator=EnhancedVocalSeparator(sr, backend=backend))
+
+    # every rank gets its own seeded track (C3-style seeds 100 + rank); rank 0 of a 1-GPU run uses the C2 seed
+    seed = 2 if world == 1 else 100 + rank
+    mix = signals.c2_song(args.track_seconds, seed=seed)
+    mix_dev = hip.to_device(mix)
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        splitter.split_track(mix, audio_dev=mix_dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
+    unet_ms = stft_ms = istft_ms = 0.0
+    items = 0
+    phases = {"separate_s": 0.0, "detect_s": 0.0, "finalize_s": 0.0}
+    summaries = []
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        ts = time.perf_counter()
+        res = splitter.split_track(mix, audio_dev=mix_dev)
+        st = res["gpu_meta"].get("gpu_pipeline_stage_ms", {})
+        unet_ms += st.get("unet_ms", 0.0); stft_ms += st.get("stft_ms", 0.0); istft_ms += st.get("istft_ms", 0.0)
+        items += int(st.get("n_items", 0))
+        for k in phases:
+            phases[k] += res["timings"].get(k, 0.0)
+        summaries.append(batch.summarize(rank * args.steps + step, res["sample_boundaries"], args.track_seconds,
+                                         {"step_s": time.perf_counter() - ts}))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    all_summaries = batch.gather_summaries(summaries)      # batch completion (RCCL barrier + all_gather_object)
+
+    if rank == 0:
+        total_audio = args.track_seconds * args.steps * world
+        flops = spec.flops_per_item() * items
+        achieved = flops / (unet_ms / 1e3) / 1e12 if unet_ms > 0 else 0.0
+        out = {
+            "metric": METRIC, "value": round(total_audio / elapsed, 3), "unit": "audio-s/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: 4-min 44.1 kHz synthetic song (stereo generator, mono down-mix), chunked MDX23 "
+                            "separation (full-size TFC-TDF, seeded synthetic weights) + TrackFeatureCache + chunked VAD + "
+                            "PureVocalPauseDetector + quiet-guard; one track per step, resident in HBM",
+                "track_seconds": args.track_seconds, "chunks_per_track": len(res["gpu_meta"].get("gpu_pipeline_config", {})) and
+                res["gpu_meta"].get("gpu_pipeline_chunks"), "unet_items_per_track": items // max(1, args.steps),
+                "items_per_forward": args.items_per_forward, "tracks_per_gpu": args.steps, "sharding": "track-per-rank",
+                "real_time_factor": round(total_audio / elapsed / world, 2),
+            },
+            "roofline": {
+                "kernel": "tfc_tdf_unet_forward (PyTorch-ROCm conv/GEMM stack: MIOpen + rocBLAS f32 kernels, one forward = "
+                          f"{args.items_per_forward} items)",
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "flops_per_item": spec.flops_per_item(), "items": items, "unet_ms_total": round(unet_ms, 2),
+                "share_of_step": round(unet_ms / 1e3 / max(1e-9, elapsed), 3),
+            },
+            "phases_ms_per_step": {"separate": round(phases["separate_s"] / args.steps * 1e3, 2),
+                                   "detect": round(phases["detect_s"] / args.steps * 1e3, 2),
+                                   "finalize": round(phases["finalize_s"] / args.steps * 1e3, 2),
+                                   "mdx_stft": round(stft_ms / args.steps, 2), "unet": round(unet_ms / args.steps, 2),
+                                   "mdx_istft": round(istft_ms / args.steps, 2)},
+            "n_boundaries": all_summaries[0]["n_boundaries"], "boundaries_sha1": all_summaries[0]["boundaries_sha1"],
+            "tracks_completed": len(all_summaries),
+        }
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds, weights, spec)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

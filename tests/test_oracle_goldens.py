@@ -1,0 +1,143 @@
+"""The oracle against the committed golden fixtures (written by tests/golden/make_golden.py from the
+reference's own Python in the build container).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from audio_cut_amd.testing import signals
+from oracle import chunking as OC, config as OCFG, detector as OD, e2e as OE, features as OF, refine as OR, vad as OV
+
+SR = 44100
+
+
+def test_effective_config_matches_reference_dump(golden_dir):
+    dump = json.loads((golden_dir / "config_effective.json").read_text())["values"]
+    for key, val in dump.items():
+        assert OCFG.get_config(key, "<absent>") == val, key
+    from audio_cut_amd import config as PCFG          # the product keeps its own copy of the same values
+    for key, val in dump.items():
+        assert PCFG.get_config(key, "<absent>") == val, key
+
+
+def test_chunk_schedule_golden(golden_dir):
+    g = np.load(golden_dir / "chunk_schedule.npz")
+    rows = g["rows"]
+    for total in np.unique(rows[:, 0]):
+        ref = rows[rows[:, 0] == total][:, 1:]
+        got = np.array([[p.index, p.start_s, p.end_s, p.halo_left_s, p.halo_right_s] for p in OC.chunk_plan(float(total))])
+        assert np.array_equal(got, ref), total
+    alt = np.array([[p.start_s, p.end_s, p.halo_left_s, p.halo_right_s] for p in OC.chunk_plan(33.0, 8.0, 3.0, 1.0)])
+    assert np.array_equal(alt, g["alt"])
+    assert [len(OC.chunk_plan(t)) for t in (60.0, 240.0, 1800.0)] == [8, 32, 240]
+
+
+def test_derive_golden(golden_dir):
+    rows = np.load(golden_dir / "derive.npz")["rows"]
+    adapt = OCFG.get_config("pure_vocal_detection.relative_threshold_adaptation", {})
+    for bpm, mdd, peak, rms, min_pause in rows:
+        th = OD.resolve_threshold(0.26, adapt, None if bpm < 0 else float(bpm), None if mdd < 0 else float(mdd))
+        assert (th.peak_ratio, th.rms_ratio) == (peak, rms)
+        assert OD.resolve_min_pause(0.5, 1.0, None if bpm < 0 else float(bpm)) == min_pause
+
+
+def _refine_case(seed, n_s, holes):
+    rng = np.random.default_rng(int(seed))
+    n = int(SR * n_s); t = np.arange(n) / SR
+    env = np.clip(np.sin(2 * np.pi * 0.13 * (int(seed) + 1) * t), 0, None) ** 2
+    mix = (rng.standard_normal(n) * 0.1 * env + 0.3 * env * np.sin(np.arange(n) * 0.05)).astype(np.float32)
+    voc = (0.7 * mix + rng.standard_normal(n).astype(np.float32) * 0.01 * env).astype(np.float32)
+    if holes:
+        a = int(n * 0.3); mix[a:a + SR] = 0; voc[a:a + SR] = 0
+    pts = np.stack([rng.uniform(0, n_s, 24), rng.uniform(0, 1, 24)], axis=1)
+    return mix, voc, pts
+
+
+@pytest.mark.parametrize("case", [0, 3])
+def test_refine_golden(golden_dir, case):
+    g = np.load(golden_dir / "refine.npz")
+    seed, n_s, holes, floor_db = g[f"c{case}_params"]
+    mix, voc, pts = _refine_case(seed, n_s, bool(holes))
+    kw = dict(min_gap_s=1.2, max_keep=200, guard_db=1.5, search_right_ms=450.0, guard_win_ms=80.0, floor_db=float(floor_db))
+    for legacy, tag in ((False, "live"), (True, "legacy")):
+        OR.LEGACY_PROMOTION = legacy
+        out = OR.finalize_cut_points(SR, mix, voc, [OR.Cut(float(a), float(b)) for a, b in pts], **kw)
+        assert out.sample_boundaries == g[f"c{case}_boundaries_{tag}"].tolist()
+        assert np.array_equal(np.array([a.final_time for a in out.adjustments]), g[f"c{case}_final_times_{tag}"])
+    OR.LEGACY_PROMOTION = True
+    lk = OR.prepare_quiet_lookup(voc, SR, 80.0, float(floor_db))
+    assert np.array_equal(lk.rms_db[::997], g[f"c{case}_db_dec"])
+    assert np.array_equal(lk.next_quiet[::997], g[f"c{case}_nq_dec"])
+
+
+def test_reference_known_answer_boundaries():
+    """tests/unit/test_cutting_consistency.py:20-46 of the reference: sample_boundaries == [0, 40, 80, 120]."""
+    out = OR.finalize_cut_points(10, np.zeros(120, np.float32), None, [OR.Cut(4.0, 0.9), OR.Cut(8.0, 0.9)], min_gap_s=1.0,
+                                 enable_mix_guard=False, enable_vocal_guard=False, zero_cross_win_ms=0.0)
+    assert out.sample_boundaries == [0, 40, 80, 120]
+
+
+def _fake_vad(chunk):
+    blk = 2205
+    n = len(chunk) // blk
+    act = np.abs(chunk[: n * blk]).reshape(n, blk).mean(axis=1) > 0.02
+    return [{"start": a * blk, "end": b * blk} for a, b, v in OD._runs(act) if v]
+
+
+def test_chunk_vad_golden(golden_dir):
+    g = np.load(golden_dir / "chunk_vad.npz")
+    voc = signals.vocal_like(40.0, seed=11)
+    ora = OV.ChunkVadOracle(SR, 120.0, 0.2, _fake_vad)
+    for p in OC.chunk_plan(40.0):
+        a = int(round(p.start_s * SR)); b = int(round(p.end_s * SR))
+        ora.process_chunk(p, voc[a:b], SR)
+    segs = ora.finalize()
+    assert np.array_equal(np.array([[s["start"], s["end"]] for s in segs]), g["segments"])
+    assert np.array_equal(np.array(ora.to_focus_windows()), g["focus"])
+
+
+def test_features_and_detector_golden(golden_dir):
+    g = np.load(golden_dir / "features_detector.npz")
+    mix = signals.c2_song(27.0, seed=21)
+    ob = OF.ChunkFeatureOracle(SR)
+    for p in OC.chunk_plan(27.0):
+        a = int(round(p.start_s * SR)); b = min(len(mix), int(round(p.end_s * SR)))
+        ob.add_chunk(p, mix[a:b], SR)
+    oc = ob.finalize(mix)
+    assert np.array_equal(oc.rms_series, g["cache_rms"]) and np.array_equal(oc.spectral_flatness, g["cache_flat"])
+    assert np.array_equal(oc.onset_envelope, g["cache_onset"]) and np.array_equal(oc.onset_frames, g["cache_onset_frames"])
+    assert np.array_equal(oc.mdd_series, g["cache_mdd"]) and np.array_equal(oc.beat_times, g["cache_beat_times"])
+    assert np.array_equal(np.asarray(oc.tempo_curve), g["cache_tempo_curve"])
+    sc = g["cache_scalars"]
+    assert (float(oc.bpm_features.main_bpm), oc.bpm_features.beat_strength, oc.bpm_features.tempo_variance,
+            oc.global_mdd, oc.rms_max, oc.onset_max) == tuple(sc)
+
+    def arr(ps):
+        return np.array([[p.start_time, p.end_time, p.confidence, p.cut_point] for p in ps], dtype=np.float64).reshape(-1, 4)
+
+    x = signals.c1_sine_silence(30.0, seed=1)
+    assert np.array_equal(arr(OD.detect_pure_vocal_pauses(x, SR, enable_mdd_enhancement=True, original_audio=x)), g["c1_pauses"])
+    voc = signals.vocal_like(27.0, seed=21)
+    vad = [{"start": 1.0, "end": 6.2, "duration": 5.2}, {"start": 7.1, "end": 13.0, "duration": 5.9},
+           {"start": 13.6, "end": 20.5, "duration": 6.9}, {"start": 21.4, "end": 26.5, "duration": 5.1}]
+    p_vad = OD.detect_pure_vocal_pauses(voc, SR, enable_mdd_enhancement=True, original_audio=mix, feature_cache=oc, vad_segments=vad)
+    p_no = OD.detect_pure_vocal_pauses(voc, SR, enable_mdd_enhancement=True, original_audio=mix, feature_cache=oc, vad_segments=[])
+    assert np.array_equal(arr(p_vad), g["c2_pauses_vad"]) and np.array_equal(arr(p_no), g["c2_pauses_novad"])
+    markers = OD.vocal_presence_markers(voc, SR)
+    assert np.array_equal(np.array(markers["vocal_presence_cut_points_sec"]), g["marker_times"])
+    quiet = voc.copy(); quiet[int(8 * SR): int(17 * SR)] *= 1e-3
+    assert np.array_equal(np.array(OD.no_vocal_runs(quiet, SR, 6.0)), g["no_vocal_runs"])
+    cands = [(p.cut_point, p.confidence) for p in p_no] + [(float(t), 1.0) for t in markers["vocal_presence_cut_points_sec"] if 0 < t < 27.0]
+    for legacy, tag in ((False, "live"), (True, "legacy")):
+        OR.LEGACY_PROMOTION = legacy
+        assert OE.finalize_and_filter_cuts(cands, mix, voc, SR).sample_boundaries == g[f"final_boundaries_{tag}"].tolist()
+    OR.LEGACY_PROMOTION = True
+
+
+def test_vpp_multiplier_is_structurally_one():
+    """pure_vocal_pause_detector.py:1464-1509: singing blocks are maximal True-runs, so no rest is ever counted."""
+    rng = np.random.default_rng(0)
+    for seed in range(3):
+        voc = signals.vocal_like(12.0, seed=seed)
+        mul, tag = OD.vpp_multiplier(voc, SR, 441, None)
+        assert mul == 1.0 and tag.startswith("VPP{")
