@@ -69,6 +69,10 @@ SIGNATURES = {
     "ac_mdx_assemble_ola": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "ac_mdx_chunk_vocal": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P]),
     "ac_sum_squares": (C.c_int, [_P, _P, _I64, _P, _I, _P]),
+    "ac_bias_relu_inplace": (C.c_int, [_P, _P, _P, _I64, _I, _I64, _P]),
+    "ac_bias_relu_mul_inplace": (C.c_int, [_P, _P, _P, _P, _I64, _I, _I64, _P]),
+    "ac_affine_relu_inplace": (C.c_int, [_P, _P, _P, _P, _I64, _I, _I64, _P]),
+    "ac_affine_relu_add": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I, _I64, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -268,6 +272,42 @@ class Context:
         out = torch.empty(int(total), dtype=torch.float32, device=self.device)
         _check(self.lib.ac_mdx_chunk_vocal(self._h, _ptr(wave), _ptr(chunk_len), _ptr(out_offset), _ptr(item_base),
                                            chunk_len.numel(), _ptr(out), _stream()))
+        return out
+
+    # -- U-Net epilogues (NCHW float32, in place unless stated) ----------------------------------------
+    @staticmethod
+    def _nchw(x: torch.Tensor):
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("epilogue expects a contiguous float32 NCHW tensor")
+        b, c, h, w = x.shape
+        return b * c, c, h * w
+
+    def bias_relu_(self, x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+        rows, c, inner = self._nchw(x)
+        _check(self.lib.ac_bias_relu_inplace(self._h, _ptr(x), _ptr(bias), rows, c, inner, _stream()))
+        return x
+
+    def bias_relu_mul_(self, x: torch.Tensor, bias: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
+        rows, c, inner = self._nchw(x)
+        if skip.shape != x.shape:
+            raise NativeError("skip tensor shape mismatch")
+        self._nchw(skip)
+        _check(self.lib.ac_bias_relu_mul_inplace(self._h, _ptr(x), _ptr(bias), _ptr(skip), rows, c, inner, _stream()))
+        return x
+
+    def affine_relu_(self, x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+        rows, c, inner = self._nchw(x)
+        _check(self.lib.ac_affine_relu_inplace(self._h, _ptr(x), _ptr(scale), _ptr(shift), rows, c, inner, _stream()))
+        return x
+
+    def affine_relu_add(self, y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual: torch.Tensor,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        rows, c, inner = self._nchw(y)
+        if residual.shape != y.shape:
+            raise NativeError("residual shape mismatch")
+        self._nchw(residual)
+        out = y if out is None else out
+        _check(self.lib.ac_affine_relu_add(self._h, _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), rows, c, inner, _stream()))
         return out
 
     def mean_square(self, x: torch.Tensor) -> float:

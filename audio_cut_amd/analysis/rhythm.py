@@ -45,15 +45,29 @@ def onset_detect(envelope: np.ndarray, sr: int, hop_length: int) -> np.ndarray:
     pre_avg = int(np.ceil(0.10 * sr // hop_length)); post_avg = int(np.ceil(0.10 * sr // hop_length + 1))
     wait = int(np.ceil(0.03 * sr // hop_length)); delta = 0.07
     n = env.shape[0]
-    # sliding max / mean with windows truncated at the edges, vectorised with cumulative tables
-    idx = np.arange(n)
-    lo_m = np.maximum(0, idx - pre_max); hi_m = np.minimum(n, idx + post_max)
-    lo_a = np.maximum(0, idx - pre_avg); hi_a = np.minimum(n, idx + post_avg)
+    # sliding max / mean over [i - pre, i + post), truncated at the edges.  Interior frames (full windows)
+    # are evaluated through a strided window view — row-wise np.max / np.mean give the same values as the
+    # per-frame slices — and only the <= pre+post edge frames go through the scalar loop.
     is_max = np.empty(n, dtype=bool)
     means = np.empty(n, dtype=env.dtype)
-    for i in range(n):                      # n is a few thousand frames at most
-        is_max[i] = env[i] == np.max(env[lo_m[i]:hi_m[i]])
-        means[i] = np.mean(env[lo_a[i]:hi_a[i]])
+
+    def _edge(i: int) -> None:
+        is_max[i] = env[i] == np.max(env[max(0, i - pre_max): i + post_max])
+        means[i] = np.mean(env[max(0, i - pre_avg): i + post_avg])
+
+    w_max, w_avg = pre_max + post_max, pre_avg + post_avg
+    lo = max(pre_max, pre_avg)
+    hi = n - max(post_max, post_avg) + 1            # frames [lo, hi) have full windows
+    if hi > lo and n >= max(w_max, w_avg):
+        from numpy.lib.stride_tricks import sliding_window_view
+        mx = sliding_window_view(env, w_max)[lo - pre_max: hi - pre_max].max(axis=1)
+        is_max[lo:hi] = env[lo:hi] == mx
+        means[lo:hi] = sliding_window_view(env, w_avg)[lo - pre_avg: hi - pre_avg].mean(axis=1)
+        for i in list(range(0, lo)) + list(range(hi, n)):
+            _edge(i)
+    else:
+        for i in range(n):
+            _edge(i)
     cand = np.flatnonzero(is_max & (env >= means + delta) & (env != 0))
     peaks = []
     last = -np.inf

@@ -68,8 +68,18 @@ DEFAULTS: Dict[str, Any] = {
         },
     },
     "vpbd": {
-        "enabled": True, "breath_score_scale": 0.6,
+        "enabled": True, "candidate_pool": "unified", "candidate_debug_json": True, "breath_score_scale": 0.6,
         "beat_candidates": {"enable": True, "bars_per_cut": 2, "base_score": 0.3},
+    },
+    "lyrics_alignment": {"enabled": False, "provider": "disabled", "strict": False},
+    "phrase_boundary": {
+        "word_edge_tolerance_ms": 60.0,
+        "weights": {"acoustic_pause": 0.35, "asr_gap": 0.2, "sentence_end": 0.15, "beat_affinity": 0.08, "mdd_affinity": 0.1,
+                    "breath": 0.12, "inside_word_penalty": 0.8, "singing_penalty": 0.5},
+    },
+    "global_planner": {
+        "enable": True, "hard_min_s": 2.0, "hard_max_s": 18.0, "target_min_s": 5.0, "target_max_s": 12.0,
+        "vocal_risk_weight": 0.25, "beat_conflict_weight": 0.15, "max_candidates_per_second": 2.0, "rescue_enabled": True,
     },
 }
 

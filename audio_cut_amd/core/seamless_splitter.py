@@ -47,7 +47,7 @@ def _remove_true_runs(mask: np.ndarray, max_len: int) -> np.ndarray:
 
 
 class SeamlessSplitter:
-    SUPPORTED_MODES = ("v2.2_mdd", "v2.1")
+    SUPPORTED_MODES = ("v2.2_mdd", "v2.1", "vpbd_acoustic", "vpbd_asr")
 
     def __init__(self, sample_rate: int = 44100, *, separator: Optional[EnhancedVocalSeparator] = None,
                  device: Optional[str] = None) -> None:
@@ -56,6 +56,8 @@ class SeamlessSplitter:
         backend = getattr(self.separator, "_primary_backend", None)
         self._hip: Optional["_native.Context"] = getattr(backend, "hip", None)
         self.pure_vocal_detector = PureVocalPauseDetector(sample_rate, ctx=self._hip)
+        from .vocal_phrase_boundary_detector import VocalPhraseBoundaryDetector
+        self.vpbd_detector = VocalPhraseBoundaryDetector(sample_rate)
         self._last_guard_adjustments_raw: list = []
         self._last_suppressed_cut_points: list = []
 
@@ -82,20 +84,40 @@ class SeamlessSplitter:
         marker_times = [float(t) for t in markers.get("vocal_presence_cut_points_sec", []) if t is not None]
 
         t1 = time.perf_counter()
-        pauses = self.pure_vocal_detector.detect_pure_vocal_pauses(
-            vocal_track, enable_mdd_enhancement=(mode == "v2.2_mdd"), original_audio=original_audio, feature_cache=cache,
-            vad_segments=sep.vad_segments, vocal_dev=state.get("vocal"), original_dev=state.get("mix"))
-        t_det = time.perf_counter() - t1
-        result: Dict = {"success": True, "mode": mode, "num_pauses": len(pauses), "gpu_meta": dict(sep.gpu_meta or {}),
+        is_vpbd = mode in {"vpbd_acoustic", "vpbd_asr"}
+        result: Dict = {"success": True, "mode": mode, "gpu_meta": dict(sep.gpu_meta or {}),
                         "separation_confidence": sep.separation_confidence, "backend_used": sep.backend_used,
-                        "vad_segments": sep.vad_segments, "feature_cache": cache, "pauses": pauses}
-        if not pauses:      # `:421-433`: single segment
-            result.update({"sample_boundaries": [0, len(original_audio)], "note": "no_pause_candidates",
-                           "timings": {"separate_s": t_sep, "detect_s": t_det, "finalize_s": 0.0}})
-            return result
-
-        t2 = time.perf_counter()
-        cut_candidates: List[Tuple[float, float]] = [(float(p.cut_point), float(p.confidence)) for p in pauses]
+                        "vad_segments": sep.vad_segments, "feature_cache": cache}
+        if is_vpbd:
+            # reference `:362-408`.  The smart_cut intent / AutoProfile runtime overrides applied at `:349` are
+            # product configuration policy (out of scope): VPBD runs on the base configuration.
+            vpbd = self.vpbd_detector.detect(mode=mode, vocal_track=vocal_track, original_audio=original_audio,
+                                             pure_vocal_detector=self.pure_vocal_detector, feature_cache=cache,
+                                             vad_segments=sep.vad_segments, device_state=state)
+            t_det = time.perf_counter() - t1
+            cut_candidates = [(c.t, c.score) for c in vpbd.selected_candidates]
+            rescue = [(c.t, c.score) for c in vpbd.planner_result.suppressed_candidates if float(c.score) > 0.0]
+            if not cut_candidates and rescue:
+                cut_candidates = rescue
+            result.update({"boundary_detection": vpbd.boundary_detection, "lyrics_alignment": vpbd.lyrics_alignment,
+                           "vpbd_selected_times": [c.t for c in vpbd.selected_candidates], "num_pauses": len(cut_candidates)})
+            if not cut_candidates:
+                result.update({"sample_boundaries": [0, len(original_audio)], "note": "no_vpbd_candidates",
+                               "timings": {"separate_s": t_sep, "detect_s": t_det, "finalize_s": 0.0}})
+                return result
+            t2 = time.perf_counter()
+        else:
+            pauses = self.pure_vocal_detector.detect_pure_vocal_pauses(
+                vocal_track, enable_mdd_enhancement=(mode == "v2.2_mdd"), original_audio=original_audio, feature_cache=cache,
+                vad_segments=sep.vad_segments, vocal_dev=state.get("vocal"), original_dev=state.get("mix"))
+            t_det = time.perf_counter() - t1
+            result.update({"num_pauses": len(pauses), "pauses": pauses})
+            if not pauses:      # `:421-433`: single segment
+                result.update({"sample_boundaries": [0, len(original_audio)], "note": "no_pause_candidates",
+                               "timings": {"separate_s": t_sep, "detect_s": t_det, "finalize_s": 0.0}})
+                return result
+            t2 = time.perf_counter()
+            cut_candidates = [(float(p.cut_point), float(p.confidence)) for p in pauses]
         min_pure_music = float(get_config("quality_control.pure_music_min_duration", 0.0))
         if min_pure_music > 0.0:
             for a, b in self._find_no_vocal_runs(vocal_track, min_pure_music, vocal_dev=state.get("vocal")):

@@ -126,7 +126,7 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             logger.warning("[MDX23Hip] no weights supplied: using seeded synthetic TFC-TDF weights (seed=%d)", self._seed)
             w = synth_weights(self._spec, seed=self._seed)
         self._weights = w
-        self._net = TfcTdfNet(w, self._spec).to(self._ctx.device).eval()
+        self._net = TfcTdfNet(w, self._spec, hip=self._ctx).to(self._ctx.device).eval()
         self.reset_performance_metrics()
 
     def describe_input(self) -> Optional[dict]:
@@ -195,10 +195,10 @@ class MDX23HipBackend(IVocalSeparatorBackend):
         d_wi = hip.to_device(np.asarray(wi_items, np.int32))
         wave = torch.empty((n_items, 2, ITEM_LEN), dtype=torch.float32, device=hip.device)
         step = max(1, self.max_items_per_forward)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timings is not None else None
-        t_stft = t_net = t_istft = 0.0
+        events: List[List[torch.cuda.Event]] = []     # per sub-batch: [before stft, before net, before istft, after istft]
         for a in range(0, n_items, step):
             b = min(n_items, a + step)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timings is not None else None
             if ev: ev[0].record()
             spec = hip.mdx_stft(track_dev, d_cs[a:b].contiguous(), d_cl[a:b].contiguous(), d_wi[a:b].contiguous())
             if ev: ev[1].record()
@@ -208,8 +208,8 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             wave[a:b] = hip.mdx_istft(out.contiguous())
             del out
             if ev:
-                ev[3].record(); ev[3].synchronize()
-                t_stft += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_istft += ev[2].elapsed_time(ev[3])
+                ev[3].record()
+                events.append(ev)
         d_chunk_start = hip.to_device(np.asarray([r[0] for r in ranges], np.int64))
         d_chunk_len = hip.to_device(np.asarray([r[1] - r[0] for r in ranges], np.int64))
         d_es = hip.to_device(np.asarray([r[2] for r in ranges], np.int64)); d_ee = hip.to_device(np.asarray([r[3] for r in ranges], np.int64))
@@ -224,6 +224,11 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             vocal, inst = other, vocal_like
             chunk_mix = torch.cat([track_dev[cs:ce] for cs, ce, _, _ in ranges])
             chunk_vocal = chunk_mix - chunk_vocal
+        t_stft = t_net = t_istft = 0.0
+        if events:                 # one synchronisation for the whole track, after everything has been queued
+            events[-1][3].synchronize()
+            for ev in events:
+                t_stft += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_istft += ev[2].elapsed_time(ev[3])
         self._perf["chunks"] += float(len(ranges))
         self._perf["compute_ms"] += t_stft + t_net + t_istft
         self._perf["max_alloc_bytes"] = max(self._perf["max_alloc_bytes"], float(torch.cuda.max_memory_allocated(hip.device)))

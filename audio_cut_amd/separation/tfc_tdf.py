@@ -253,7 +253,22 @@ class _Block(nn.Module):
             self.register_buffer(f"ls{j}", torch.from_numpy(s.astype(np.float32)).view(1, -1, 1, 1))
             self.register_buffer(f"lb{j}", torch.from_numpy(sh.astype(np.float32)).view(1, -1, 1, 1))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, hip=None, probe=None) -> torch.Tensor:
+        if hip is not None:
+            # dense contractions in MIOpen / rocBLAS, every elementwise hop as ONE fused HIP pass (ac_epilogue.hip)
+            for j in range(self.l):
+                if probe is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    y = F.conv2d(x, getattr(self, f"cw{j}"), None, padding=self.pad)
+                    e1.record()
+                    probe.append((e0, e1, 2.0 * x.shape[0] * x.shape[1] * x.shape[1] * 9 * x.shape[2] * x.shape[3]))
+                else:
+                    y = F.conv2d(x, getattr(self, f"cw{j}"), None, padding=self.pad)
+                x = hip.bias_relu_(y, getattr(self, f"cb{j}"))
+            y = hip.affine_relu_(F.linear(x, self.lw0), self.ls0.view(-1), self.lb0.view(-1))
+            y = F.linear(y, self.lw1)
+            return hip.affine_relu_add(y, self.ls1.view(-1), self.lb1.view(-1), x)
         for j in range(self.l):
             x = F.relu_(F.conv2d(x, getattr(self, f"cw{j}"), getattr(self, f"cb{j}"), padding=self.pad))
         y = x
@@ -266,9 +281,11 @@ class _Block(nn.Module):
 class TfcTdfNet(nn.Module):
     """Inference-only TFC-TDF v2 with folded BN.  Input/output `[B, 4, dim_f, T]` float32."""
 
-    def __init__(self, weights: Weights, spec: TfcTdfSpec = TfcTdfSpec()):
+    def __init__(self, weights: Weights, spec: TfcTdfSpec = TfcTdfSpec(), hip=None):
         super().__init__()
         self.spec = spec
+        self.hip = hip          # audio_cut_amd._native.Context: enables the fused HIP epilogues on device tensors
+        self.conv_probe = None  # set to a list to collect (start event, end event, flops) per 3x3 conv launch (bench.py)
         w = weights
         wf, bf = _fold(w["first_conv.weight"], w["first_conv.bias"], w, "first_bn", spec.bn_eps, 0)
         self.register_buffer("first_w", torch.from_numpy(wf))
@@ -297,8 +314,21 @@ class TfcTdfNet(nn.Module):
         conv and right before its last one (1x1 convs commute with the transpose), so the HIP STFT writes
         and the HIP iSTFT reads this layout directly and no transpose is ever materialised."""
         n = self.spec.n_levels
-        x = F.relu_(F.conv2d(spec_tf, self.first_w, self.first_b))
+        hip = self.hip if (self.hip is not None and spec_tf.is_cuda) else None
         skips: List[torch.Tensor] = []
+        if hip is not None:
+            x = hip.bias_relu_(F.conv2d(spec_tf, self.first_w, None), self.first_b)
+            for i in range(n):
+                x = self.enc[i](x, hip, self.conv_probe)
+                skips.append(x)
+                x = hip.bias_relu_(F.conv2d(x, getattr(self, f"ds_w{i}"), None, stride=2), getattr(self, f"ds_b{i}"))
+            x = self.bottleneck(x, hip, self.conv_probe)
+            for i in range(n):
+                x = F.conv_transpose2d(x, getattr(self, f"us_w{i}"), None, stride=2)
+                x = hip.bias_relu_mul_(x, getattr(self, f"us_b{i}"), skips.pop())
+                x = self.dec[i](x, hip, self.conv_probe)
+            return F.conv2d(x, self.final_w, self.final_b)
+        x = F.relu_(F.conv2d(spec_tf, self.first_w, self.first_b))
         for i in range(n):
             x = self.enc[i](x)
             skips.append(x)

@@ -40,7 +40,12 @@ def cpu_baseline(sample_s: float, weights, spec) -> dict:
     from audio_cut_amd.testing import signals
     from oracle import e2e as OE, refine as OR
     OR.LEGACY_PROMOTION = True
-    threads = int(os.environ.get("AC_CPU_BASELINE_THREADS", os.cpu_count() or 1))
+    # the GPU box shares its host: one GPU's CPU share is 16 cores, whatever os.cpu_count() says
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = int(os.environ.get("AC_CPU_BASELINE_THREADS", min(16, avail)))
     torch.set_num_threads(threads)
     mix = signals.c2_song(sample_s, seed=2)
     t0 = time.perf_counter()
@@ -50,6 +55,33 @@ def cpu_baseline(sample_s: float, weights, spec) -> dict:
             "sample": f"first {sample_s:g} s of the C2 track generator (seed 2), full oracle path, one pass",
             "seconds": round(dt, 2), "phases_s": {k: round(v, 3) for k, v in res.timings.items()},
             "n_boundaries": len(res.sample_boundaries)}
+
+
+DOMINANT = "miopenSp3AsmConv_v30_3_1_gfx9_fp32_f2x3_stride1"
+
+
+def roofline_conv(probe, conv_ms: float, conv_flops: float, elapsed: float) -> dict:
+    """The dominant kernel: MIOpen's Winograd 3x3 conv, one launch per `F.conv2d` of the 33 3x3 convs of a forward.
+    `achieved` = algorithmic FLOPs (2*B*C*C*9*H*W per launch) / HIP-event time around the launches of the timed
+    region; `traffic` = HBM bytes per launch from the committed PMC passes (profiles/*_pmc_summary.json)."""
+    n = max(1, len(probe))
+    achieved = conv_flops / (conv_ms / 1e3) / 1e12 if conv_ms > 0 else 0.0
+    traffic = None
+    for cand in sorted((ROOT / "profiles").glob("*_pmc_summary.json"), reverse=True):
+        try:
+            k = json.loads(cand.read_text())["kernels"].get(DOMINANT)
+            if k:
+                traffic = round(k["hbm_bytes_per_launch"])
+                break
+        except Exception:
+            pass
+    return {
+        "kernel": DOMINANT + " (MIOpen Winograd F(2x2,3x3) f32 asm, one launch per 3x3 conv of the U-Net)",
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+        "launches": len(probe), "avg_launch_ms": round(conv_ms / n, 4), "flops_per_launch": conv_flops / n,
+        "share_of_step": round(conv_ms / 1e3 / max(1e-9, elapsed), 3),
+    }
 
 
 def main() -> None:
@@ -102,6 +134,7 @@ def main() -> None:
     if world > 1:
         dist.barrier()
 
+    backend.net.conv_probe = []        # HIP events around every 3x3 conv launch of the timed region (same stream)
     unet_ms = stft_ms = istft_ms = 0.0
     items = 0
     phases = {"separate_s": 0.0, "detect_s": 0.0, "finalize_s": 0.0}
@@ -126,6 +159,10 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     all_summaries = batch.gather_summaries(summaries)      # batch completion (RCCL barrier + all_gather_object)
+    probe = backend.net.conv_probe
+    backend.net.conv_probe = None
+    conv_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in probe)
+    conv_flops = sum(f for _, _, f in probe)
 
     if rank == 0:
         total_audio = args.track_seconds * args.steps * world
@@ -144,13 +181,13 @@ def main() -> None:
                 "items_per_forward": args.items_per_forward, "tracks_per_gpu": args.steps, "sharding": "track-per-rank",
                 "real_time_factor": round(total_audio / elapsed / world, 2),
             },
-            "roofline": {
-                "kernel": "tfc_tdf_unet_forward (PyTorch-ROCm conv/GEMM stack: MIOpen + rocBLAS f32 kernels, one forward = "
-                          f"{args.items_per_forward} items)",
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-                "flops_per_item": spec.flops_per_item(), "items": items, "unet_ms_total": round(unet_ms, 2),
-                "share_of_step": round(unet_ms / 1e3 / max(1e-9, elapsed), 3),
+            "roofline": roofline_conv(probe, conv_ms, conv_flops, elapsed),
+            "unet_forward": {
+                "what": "whole TFC-TDF forward (MIOpen convs + rocBLAS TDF GEMMs + fused HIP epilogues), "
+                        f"{args.items_per_forward} items per forward",
+                "achieved": round(achieved, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 4), "flops_per_item": spec.flops_per_item(), "items": items,
+                "ms_total": round(unet_ms, 2), "share_of_step": round(unet_ms / 1e3 / max(1e-9, elapsed), 3),
             },
             "phases_ms_per_step": {"separate": round(phases["separate_s"] / args.steps * 1e3, 2),
                                    "detect": round(phases["detect_s"] / args.steps * 1e3, 2),

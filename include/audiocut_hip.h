@@ -149,6 +149,24 @@ int ac_mdx_chunk_vocal(ac_ctx* ctx, const float* wave, const int64_t* chunk_len,
 /* enhanced_vocal_separator.py:490-501: float64 partial sums of x^2 (n_partials blocks, summed by the host). */
 int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int n_partials, void* stream);
 
+/* ---- U-Net epilogues ------------------------------------------------------------------------ */
+
+/* The BatchNorm / ReLU / Mul / Add nodes between the Conv / ConvTranspose / MatMul nodes of the graph the
+ * reference runs through ORT (separation/backends.py:358), as single streaming passes over NCHW float32
+ * activations (row = one (batch, channel) plane of `inner` contiguous elements, channel = row % C,
+ * inner % 4 == 0).  The dense contractions themselves stay in MIOpen / rocBLAS.
+ *   ac_bias_relu_inplace:      x = relu(x + bias[c])
+ *   ac_bias_relu_mul_inplace:  x = relu(x + bias[c]) * skip        (decoder: up-sample then multiplicative skip)
+ *   ac_affine_relu_inplace:    x = relu(x * scale[c] + shift[c])   (TDF linear 1)
+ *   ac_affine_relu_add:        out = residual + relu(y * scale[c] + shift[c])   (TDF linear 2 + residual) */
+int ac_bias_relu_inplace(ac_ctx* ctx, float* x, const float* bias, int64_t rows, int C, int64_t inner, void* stream);
+int ac_bias_relu_mul_inplace(ac_ctx* ctx, float* x, const float* bias, const float* skip, int64_t rows, int C,
+                             int64_t inner, void* stream);
+int ac_affine_relu_inplace(ac_ctx* ctx, float* x, const float* scale, const float* shift, int64_t rows, int C,
+                           int64_t inner, void* stream);
+int ac_affine_relu_add(ac_ctx* ctx, const float* y, const float* scale, const float* shift, const float* residual,
+                       float* out, int64_t rows, int C, int64_t inner, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score

@@ -284,6 +284,36 @@ def golden_features_and_detector() -> None:
     _save("features_detector.npz", **out)
 
 
+from audio_cut_amd.testing.vpbd_inputs import FixedPauses as _FixedPauses, vpbd_case  # noqa: E402
+
+
+def golden_vpbd() -> None:
+    import tempfile
+    from vocal_smart_splitter.core.vocal_phrase_boundary_detector import VocalPhraseBoundaryDetector as RefVPBD
+    from audio_cut_amd.core.vocal_phrase_boundary_detector import VocalPhraseBoundaryDetector as OurVPBD
+    out = {}
+    for case, seed in enumerate((31, 32, 33)):
+        cache, pauses, vocal = vpbd_case(seed)
+        with tempfile.TemporaryDirectory() as tmp:
+            r = RefVPBD(SR).detect(mode="vpbd_acoustic", vocal_track=vocal, original_audio=vocal, pure_vocal_detector=_FixedPauses(pauses),
+                                   feature_cache=cache, vad_segments=None, input_path="x.wav", output_dir=tmp)
+            o = OurVPBD(SR).detect(mode="vpbd_acoustic", vocal_track=vocal, original_audio=vocal, pure_vocal_detector=_FixedPauses(pauses),
+                                   feature_cache=cache, vad_segments=None, input_path="x.wav", output_dir=tmp)
+        rs = [(c.t, c.score, c.source.value) for c in r.selected_candidates]
+        os_ = [(c.t, c.score, c.source.value) for c in o.selected_candidates]
+        assert rs == os_ and len(rs) >= 4, (rs, os_)
+        assert r.boundary_detection["candidate_counts"] == o.boundary_detection["candidate_counts"]
+        rsup = [(c.t, c.score) for c in r.planner_result.suppressed_candidates]
+        osup = [(c.t, c.score) for c in o.planner_result.suppressed_candidates]
+        assert rsup == osup
+        assert [c.features for c in r.selected_candidates] == [c.features for c in o.selected_candidates]
+        out[f"c{case}_selected"] = np.array([[t, s] for t, s, _ in rs])
+        out[f"c{case}_suppressed"] = np.array(rsup).reshape(-1, 2)
+        out[f"c{case}_counts"] = np.array([r.boundary_detection["candidate_counts"][k] for k in ("acoustic", "beat", "merged", "total", "selected", "suppressed")])
+        out[f"c{case}_features"] = np.array([[c.features[k] for k in sorted(c.features)] for c in r.selected_candidates])
+    _save("vpbd.npz", **out)
+
+
 def golden_config() -> None:
     from vocal_smart_splitter.utils.config_manager import get_config
     from oracle import config as ocfg
@@ -311,4 +341,5 @@ if __name__ == "__main__":
     golden_refine()
     golden_chunk_vad()
     golden_features_and_detector()
+    golden_vpbd()
     print("all goldens generated; oracle pinned against the reference's control logic")

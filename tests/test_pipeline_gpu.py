@@ -179,3 +179,38 @@ def test_full_path_separate_detect_against_oracle(hip_ctx):
     assert sep.quality_metrics["vocal_presence_cut_points_sec"] == ref.markers["vocal_presence_cut_points_sec"]
     _assert_pauses_equal(res["pauses"], ref.pauses)
     assert res["sample_boundaries"] == ref.sample_boundaries
+
+
+def test_vpbd_acoustic_mode_against_oracle(hip_ctx):
+    """BASELINE config C4: separator + chunked VAD focus windows + VPBD pool / score / plan, then the guard.
+    Expected values: the CPU oracle's stems / cache / pauses pushed through the VPBD host logic (itself pinned to the
+    reference by tests/golden/vpbd.npz) and the oracle's finalize."""
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.core.vocal_phrase_boundary_detector import VocalPhraseBoundaryDetector
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    from audio_cut_amd.testing.vpbd_inputs import FixedPauses
+    mix = signals.c2_song(24.0, seed=6)
+    w = synth_weights(TfcTdfSpec(), seed=0)
+    backend = MDX23HipBackend(weights=w, ctx=hip_ctx)
+    backend.load_model()
+    sp = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend))
+    res = sp.split_track(mix, mode="vpbd_acoustic")
+    OR.LEGACY_PROMOTION = True
+    ref = OE.run_track(mix, SR, w)
+    vp = VocalPhraseBoundaryDetector(SR).detect(mode="vpbd_acoustic", vocal_track=ref.vocal, original_audio=mix,
+                                                pure_vocal_detector=FixedPauses(ref.pauses), feature_cache=ref.cache,
+                                                vad_segments=ref.vad_segments)
+    exp_times = [c.t for c in vp.selected_candidates]
+    assert res["vpbd_selected_times"] == exp_times and len(exp_times) >= 2
+    assert res["boundary_detection"]["candidate_counts"] == vp.boundary_detection["candidate_counts"]
+    cands = [(c.t, c.score) for c in vp.selected_candidates]
+    for a, b in OD.no_vocal_runs(ref.vocal, SR, 6.0):
+        cands += [(float(a), 1.0), (float(b), 1.0)]
+    protected = set()
+    for t in ref.markers["vocal_presence_cut_points_sec"]:
+        if 0.0 < t < len(mix) / SR:
+            cands.append((float(t), 1.0)); protected.add(int(round(t * SR)))
+    exp = set(OE.finalize_and_filter_cuts(cands, mix, ref.vocal, SR).sample_boundaries) | {s for s in protected if 0 < s < len(mix)}
+    assert res["sample_boundaries"] == sorted(exp)

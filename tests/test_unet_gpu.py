@@ -45,3 +45,23 @@ def test_unet_blocks_and_output_vs_float64(hip_ctx):
     # ONNX-shaped entry point == T-major entry point
     ytf = netg.forward_tf(x.transpose(-1, -2).contiguous().to(hip_ctx.device)).transpose(-1, -2).double().cpu()
     assert torch.equal(ytf, yg)
+
+
+def test_fused_epilogues_match_the_unfused_torch_ops(hip_ctx):
+    """TfcTdfNet with the HIP epilogues (bias+ReLU, affine+ReLU(+residual), bias+ReLU*skip) == plain PyTorch elementwise ops."""
+    spec = TfcTdfSpec()
+    w = synth_weights(spec, seed=0)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(2, 4, 32, 3072, generator=g) * 3.0).to(hip_ctx.device)
+    plain = TfcTdfNet(w, spec).to(hip_ctx.device).eval()
+    fused = TfcTdfNet(w, spec, hip=hip_ctx).to(hip_ctx.device).eval()
+    a = plain.forward_tf(x); b = fused.forward_tf(x)
+    assert float((a - b).abs().max() / a.abs().max()) < 2e-6
+    # the kernels themselves, on odd row counts
+    t = torch.randn(3, 5, 7, 12, device=hip_ctx.device); bias = torch.randn(5, device=hip_ctx.device)
+    sk = torch.randn_like(t); sc = torch.randn(5, device=hip_ctx.device)
+    assert torch.equal(hip_ctx.bias_relu_(t.clone(), bias), torch.relu(t + bias.view(1, -1, 1, 1)))
+    assert torch.equal(hip_ctx.bias_relu_mul_(t.clone(), bias, sk), torch.relu(t + bias.view(1, -1, 1, 1)) * sk)
+    ref = torch.relu(t * sc.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    assert torch.equal(hip_ctx.affine_relu_(t.clone(), sc, bias), ref)
+    assert torch.equal(hip_ctx.affine_relu_add(t.clone(), sc, bias, sk), sk + ref)
