@@ -95,18 +95,18 @@ def unet_forward(spec: torch.Tensor, w: Weights, n_levels: int = 5, l: int = 3) 
 
 
 def infer_chunk(mix_chunk: np.ndarray, w: Weights, align_hop: int = 4096, output_type: str = "vocal",
-                n_levels: int = 5, l: int = 3) -> Tuple[np.ndarray, np.ndarray]:
-    """backends.py:299-406 on the CPU."""
+                n_levels: int = 5, l: int = 3, net_fn: Optional[Callable] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """backends.py:299-406 on the CPU.  `net_fn` replaces the U-Net (e.g. identity for round-trip property tests)."""
     batch, stereo, orig = C.mdx_windows(mix_chunk, align_hop)
     spec = mdx_stft(batch)
-    out = unet_forward(spec, w, n_levels=n_levels, l=l)
+    out = net_fn(spec) if net_fn is not None else unet_forward(spec, w, n_levels=n_levels, l=l)
     wave = mdx_istft(out)
     return C.mdx_assemble(wave, stereo, orig, output_type)
 
 
 def separate_track(audio: np.ndarray, sr: int, w: Weights, *, chunk_s: float = 10.0, overlap_s: float = 2.5,
                    halo_s: float = 0.5, align_hop: int = 4096,
-                   on_chunk: Optional[Callable] = None, n_levels: int = 5, l: int = 3):
+                   on_chunk: Optional[Callable] = None, n_levels: int = 5, l: int = 3, net_fn: Optional[Callable] = None):
     """enhanced_vocal_separator.py:300-488 without the feature/VAD side channels (those are
     `on_chunk(plan, mix_chunk, vocal_chunk)` callbacks so tests can wire oracle.features / oracle.vad)."""
     total = len(audio)
@@ -118,7 +118,7 @@ def separate_track(audio: np.ndarray, sr: int, w: Weights, *, chunk_s: float = 1
         chunk = np.ascontiguousarray(audio[cs:ce], dtype=np.float32)
         if chunk.size == 0:
             continue
-        voc, inst = infer_chunk(chunk, w, align_hop, n_levels=n_levels, l=l)
+        voc, inst = infer_chunk(chunk, w, align_hop, n_levels=n_levels, l=l, net_fn=net_fn)
         if on_chunk is not None:
             on_chunk(plan, chunk, voc, (ee - es) > 0)
         outs.append((voc, inst))
