@@ -57,6 +57,7 @@ SIGNATURES = {
     "ac_onset_strength": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P]),
     "ac_tempogram_parts": (C.c_int, [_I64]),
     "ac_tempogram_reduce": (C.c_int, [_P, _P, _I64, _I, _P, _P, _P, _P, _P]),
+    "ac_yin_f0": (C.c_int, [_P, _P, _I64, _I, _I, _I, _I, C.c_double, _P, _P, _I64, _P]),
     "ac_moving_meansq_db_f64": (C.c_int, [_P, _P, _I64, _I, _P, _P]),
     "ac_next_leq_scratch": (C.c_int64, [_I64]),
     "ac_next_leq_scan": (C.c_int, [_P, _P, _I64, C.c_double, _P, _P, _P]),
@@ -186,6 +187,20 @@ class Context:
         scratch = torch.empty(parts * win, dtype=torch.float64, device=self.device)
         _check(self.lib.ac_tempogram_reduce(self._h, _ptr(env), n, win, _ptr(lp), _ptr(mean), _ptr(arg), _ptr(scratch), _stream()))
         return mean, arg
+
+    def yin_f0(self, x: torch.Tensor, sr: int, fmin: float, fmax: float, frame_length: int = 2048, hop: int = 512,
+               threshold: float = 0.1, want_cmnd: bool = False):
+        """librosa.yin on the GPU: (f0 [frames] float64 on the host, optional cmnd device tensor [frames, lags])."""
+        self._chk_f32(x)
+        n = x.numel()
+        min_period = max(int(np.floor(sr / fmax)), 1)
+        max_period = min(int(np.ceil(sr / fmin)), frame_length - frame_length // 2 - 1)
+        nf = 1 + n // hop
+        period = torch.empty(nf, dtype=torch.float64, device=self.device)
+        cmnd = torch.empty((nf, max_period - min_period + 1), dtype=torch.float32, device=self.device) if want_cmnd else None
+        _check(self.lib.ac_yin_f0(self._h, _ptr(x), n, frame_length, hop, min_period, max_period, float(threshold),
+                                  _ptr(period), _ptr(cmnd), nf, _stream()))
+        return float(sr) / period.cpu().numpy(), cmnd
 
     # -- guard ---------------------------------------------------------------------------------------
     def moving_meansq_db(self, x: torch.Tensor, win: int) -> torch.Tensor:

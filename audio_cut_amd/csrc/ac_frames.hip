@@ -361,3 +361,156 @@ extern "C" int ac_tempogram_reduce(ac_ctx* ctx, const float* env, int64_t n, int
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
+
+// =================================================================================================
+// YIN fundamental frequency ("autocorrelation F0"): the deterministic first stage of librosa.pyin
+// (pure_vocal_pause_detector.py:422-428) = librosa.yin.  Per centred frame of `frame_length` samples
+// (W = frame_length/2): acf[tau] = sum_{j=1..W} y_j y_{j+tau}, E[tau] = sum_{j=tau+1..tau+W} y_j^2,
+// d[tau] = E[0] + E[tau] - 2 acf[tau], cumulative-mean-normalised, first trough under the threshold
+// (else the global minimum) with parabolic refinement.  One workgroup per frame, frame in LDS, float64;
+// |acf| and |E| below 1e-6 are snapped to zero like librosa does on its float32 FFT result.
+// =================================================================================================
+#define YIN_MAX_FRAME 4096
+#define NQ_INF_I 0x7fffffffffffffffLL
+#define YIN_MAX_LAGS 2048
+
+__global__ __launch_bounds__(256) void k_yin(const float* __restrict__ x, int64_t n, int frame_length, int hop,
+                                             int min_period, int max_period, double threshold,
+                                             double* __restrict__ period_out, float* __restrict__ cmnd_out) {
+    extern __shared__ double s_dyn[];
+    double* s_x = s_dyn;                               // frame_length
+    double* s_cs = s_x + frame_length;                 // frame_length + 1 (exclusive prefix of squares)
+    double* s_yin = s_cs + frame_length + 1;           // max_period + 1
+    double* s_cm = s_yin + (max_period + 1);           // max_period + 1 (cmnd, index by tau)
+    __shared__ double s_red[4];
+    __shared__ double s_scan[4];
+    __shared__ long long s_idx[4];
+    const int64_t f = blockIdx.x;
+    const int W = frame_length / 2;
+    const int64_t s0 = f * (int64_t)hop - frame_length / 2;
+    for (int i = threadIdx.x; i < frame_length; i += 256) {
+        const int64_t g = s0 + i;
+        s_x[i] = (g >= 0 && g < n) ? (double)x[g] : 0.0;
+    }
+    __syncthreads();
+    // exclusive prefix sums of squares: cs[k] = sum_{j<k} x_j^2   (contiguous chunk per thread + block scan)
+    {
+        const int per = (frame_length + 255) / 256;
+        const int e0 = threadIdx.x * per;
+        double loc = 0.0;
+        for (int q = 0; q < per; ++q) { const int e = e0 + q; if (e < frame_length) loc += s_x[e] * s_x[e]; }
+        // block exclusive scan of `loc`
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        double inc = loc;
+        for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(inc, off, AC_WAVE); if (lane >= off) inc += t; }
+        if (lane == 63) s_scan[w] = inc;
+        __syncthreads();
+        double base = 0.0;
+        for (int q = 0; q < w; ++q) base += s_scan[q];
+        const double prev = __shfl_up(inc, 1, AC_WAVE);
+        double run = base + (lane > 0 ? prev : 0.0);
+        for (int q = 0; q < per; ++q) {
+            const int e = e0 + q;
+            if (e < frame_length) { s_cs[e] = run; run += s_x[e] * s_x[e]; }
+        }
+        if (e0 < frame_length && e0 + per >= frame_length) s_cs[frame_length] = run;   // total, written by the thread owning the last chunk
+    }
+    __syncthreads();
+    // difference function for tau = 0 .. max_period
+    const double e_zero_raw = s_cs[W + 1] - s_cs[1];
+    const double e_zero = fabs(e_zero_raw) < 1e-6 ? 0.0 : e_zero_raw;
+    for (int tau = threadIdx.x; tau <= max_period; tau += 256) {
+        double acf = 0.0;
+        for (int j = 1; j <= W; ++j) acf += s_x[j] * s_x[j + tau];
+        if (fabs(acf) < 1e-6) acf = 0.0;
+        double e = s_cs[tau + W + 1] - s_cs[tau + 1];
+        if (fabs(e) < 1e-6) e = 0.0;
+        s_yin[tau] = e_zero + e - 2.0 * acf;
+    }
+    __syncthreads();
+    // cumulative mean over tau = 1 .. max_period, then cmnd[tau] = yin[tau] / (cm[tau] + tiny_f32)
+    {
+        const int per = (max_period + 255) / 256;
+        const int t0 = 1 + threadIdx.x * per;
+        double loc = 0.0;
+        for (int q = 0; q < per; ++q) { const int t = t0 + q; if (t <= max_period) loc += s_yin[t]; }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        double inc = loc;
+        for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(inc, off, AC_WAVE); if (lane >= off) inc += t; }
+        __syncthreads();
+        if (lane == 63) s_scan[w] = inc;
+        __syncthreads();
+        double base = 0.0;
+        for (int q = 0; q < w; ++q) base += s_scan[q];
+        const double prev = __shfl_up(inc, 1, AC_WAVE);
+        double run = base + (lane > 0 ? prev : 0.0);
+        for (int q = 0; q < per; ++q) {
+            const int t = t0 + q;
+            if (t <= max_period) {
+                run += s_yin[t];
+                // librosa holds these series in float32: round numerator and denominator there
+                const float num = (float)s_yin[t];
+                const float den = (float)(run / (double)t);
+                s_cm[t] = (double)(num / (den + 1.17549435e-38f));
+            }
+        }
+    }
+    __syncthreads();
+    const int n_lags = max_period - min_period + 1;
+    if (cmnd_out) {
+        float* row = cmnd_out + f * (int64_t)n_lags;
+        for (int i = threadIdx.x; i < n_lags; i += 256) row[i] = (float)s_cm[min_period + i];
+    }
+    // first trough below the threshold, else the first global minimum (indices relative to min_period)
+    long long first = NQ_INF_I;
+    double gmin = INFINITY; long long gidx = NQ_INF_I;
+    for (int i = threadIdx.x; i < n_lags; i += 256) {
+        const double v = s_cm[min_period + i];
+        const double left = s_cm[min_period + (i > 0 ? i - 1 : 0)];
+        const double right = s_cm[min_period + (i < n_lags - 1 ? i + 1 : n_lags - 1)];
+        bool trough = (i == 0) ? (n_lags > 1 && v < s_cm[min_period + 1]) : (v < left && v <= right);
+        if (trough && v < threshold && i < first) first = i;
+        if (v < gmin) { gmin = v; gidx = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long of = __shfl_down(first, off, AC_WAVE); first = of < first ? of : first;
+        const double ov = __shfl_down(gmin, off, AC_WAVE); const long long oi = __shfl_down(gidx, off, AC_WAVE);
+        if (ov < gmin || (ov == gmin && oi < gidx)) { gmin = ov; gidx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_idx[threadIdx.x >> 6] = first; s_red[threadIdx.x >> 6] = gmin; s_scan[threadIdx.x >> 6] = (double)gidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long fi = s_idx[0]; double gm = s_red[0]; long long gi = (long long)s_scan[0];
+        for (int w = 1; w < 4; ++w) {
+            fi = s_idx[w] < fi ? s_idx[w] : fi;
+            const long long oi = (long long)s_scan[w];
+            if (s_red[w] < gm || (s_red[w] == gm && oi < gi)) { gm = s_red[w]; gi = oi; }
+        }
+        const long long pick = (fi != NQ_INF_I) ? fi : gi;
+        double shift = 0.0;
+        if (pick > 0 && pick < n_lags - 1) {
+            // float32 arithmetic like librosa's parabolic interpolation on the float32 cmnd
+            const float xm = (float)s_cm[min_period + pick - 1], x0 = (float)s_cm[min_period + pick], xp = (float)s_cm[min_period + pick + 1];
+            const float a = xp + xm - 2.0f * x0;
+            const float b = (xp - xm) / 2.0f;
+            if (!(fabsf(b) >= fabsf(a))) shift = (double)(-b / a);
+        }
+        period_out[f] = (double)min_period + (double)pick + shift;
+    }
+}
+
+extern "C" int ac_yin_f0(ac_ctx* ctx, const float* x, int64_t n, int frame_length, int hop, int min_period, int max_period,
+                         double threshold, double* period_out, float* cmnd_out, int64_t n_frames, void* stream) {
+    AC_REQUIRE(ctx && x && period_out, "null pointer");
+    AC_REQUIRE(n > 0 && hop > 0 && frame_length >= 4 && frame_length <= YIN_MAX_FRAME && (frame_length % 2) == 0, "frame_length in [4, 4096], even");
+    AC_REQUIRE(min_period >= 1 && max_period > min_period + 1 && max_period <= frame_length - frame_length / 2 - 1 && max_period < YIN_MAX_LAGS,
+               "1 <= min_period < max_period <= frame_length/2 - 1");
+    AC_REQUIRE(n_frames == 1 + n / hop && n_frames < (1LL << 31), "n_frames != 1 + n/hop");
+    const size_t lds = ((size_t)2 * frame_length + 1 + 2 * ((size_t)max_period + 1)) * sizeof(double);
+    if (lds > 64 * 1024)
+        AC_CHECK_HIP(hipFuncSetAttribute((const void*)k_yin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_yin, dim3((unsigned)n_frames), dim3(256), lds, (hipStream_t)stream, x, n, frame_length, hop, min_period,
+                       max_period, threshold, period_out, cmnd_out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

@@ -81,6 +81,14 @@ int ac_tempogram_parts(int64_t n);
 int ac_tempogram_reduce(ac_ctx* ctx, const float* env, int64_t n, int win, const double* logprior,
                         double* mean_out, int32_t* argmax_out, double* scratch, void* stream);
 
+/* librosa.yin — the deterministic autocorrelation-F0 stage of librosa.pyin(fmin=C2, fmax=C7, frame 2048, hop 441)
+ * (core/pure_vocal_pause_detector.py:422-428, dormant multi-feature branch): centred frames, difference function
+ * over tau in [0, max_period] with W = frame_length/2, cumulative-mean normalisation, first trough below
+ * `threshold` (else the global minimum), parabolic refinement.  period_out[n_frames] f64 (f0 = sr / period);
+ * cmnd_out[n_frames * (max_period - min_period + 1)] f32 frame-major may be NULL. */
+int ac_yin_f0(ac_ctx* ctx, const float* x, int64_t n, int frame_length, int hop, int min_period, int max_period,
+              double threshold, double* period_out, float* cmnd_out, int64_t n_frames, void* stream);
+
 /* ---- quiet guard / cut refinement --------------------------------------------------------- */
 
 /* cutting/refine.py:170-174: float64 moving mean of x^2 (np.convolve(...,'same'), window `win`)

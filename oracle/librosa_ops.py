@@ -420,3 +420,58 @@ def install_as_librosa() -> types.ModuleType:
                       ("librosa.onset", onset), ("librosa.beat", beat), ("librosa.util", util)):
         sys.modules[name] = mod
     return lib
+
+
+# ---------------------------------------------------------------------------
+# YIN fundamental frequency (first stage of librosa.pyin, pure_vocal_pause_detector.py:422-428)
+# ---------------------------------------------------------------------------
+
+def cmnd_frames(y: np.ndarray, sr: float, fmin: float, fmax: float, frame_length: int = 2048, hop_length: int = 512,
+                center: bool = True) -> Tuple[np.ndarray, int, int]:
+    """librosa.core.pitch._cumulative_mean_normalized_difference over centred frames ->
+    (cmnd [max_period-min_period+1, n_frames], min_period, max_period).  FFT autocorrelation in the input
+    dtype, |acf| and |energy| below 1e-6 snapped to zero, exactly as librosa does."""
+    win_length = frame_length // 2
+    y = np.asarray(y)
+    if center:
+        y = np.pad(y, frame_length // 2, mode="constant")
+    y_frames = frame(y, frame_length, hop_length)
+    min_period = max(int(np.floor(sr / fmax)), 1)
+    max_period = min(int(np.ceil(sr / fmin)), frame_length - win_length - 1)
+    out = np.empty((max_period - min_period + 1, y_frames.shape[1]), dtype=y.dtype)
+    for s in range(0, y_frames.shape[1], 2048):
+        blk = y_frames[:, s:s + 2048]
+        a = np.fft.rfft(blk, frame_length, axis=0)
+        b = np.fft.rfft(blk[win_length:0:-1, :], frame_length, axis=0)
+        acf = np.fft.irfft(a * b, frame_length, axis=0)[win_length:, :].astype(y.dtype)
+        acf[np.abs(acf) < 1e-6] = 0
+        energy = np.cumsum(blk ** 2, axis=0)
+        energy = energy[win_length:, :] - energy[:-win_length, :]
+        energy[np.abs(energy) < 1e-6] = 0
+        yin = energy[:1, :] + energy - 2 * acf
+        num = yin[min_period: max_period + 1, :]
+        tau = np.arange(1, max_period + 1).reshape(-1, 1)
+        cum_mean = np.cumsum(yin[1: max_period + 1, :], axis=0) / tau
+        den = cum_mean[min_period - 1: max_period, :]
+        out[:, s:s + blk.shape[1]] = num / (den + tiny(den))
+    return out, min_period, max_period
+
+
+def yin(y: np.ndarray, fmin: float, fmax: float, sr: float = 22050, frame_length: int = 2048, hop_length: int = 512,
+        trough_threshold: float = 0.1, center: bool = True) -> np.ndarray:
+    """librosa.yin: first CMND trough below the threshold (else the global minimum) + parabolic refinement."""
+    cm, min_period, _ = cmnd_frames(y, sr, fmin, fmax, frame_length, hop_length, center)
+    shifts = np.zeros_like(cm)
+    a = cm[2:] + cm[:-2] - 2 * cm[1:-1]
+    b = (cm[2:] - cm[:-2]) / 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        shifts[1:-1] = np.where(np.abs(b) >= np.abs(a), 0, -b / a)
+    pad = np.pad(cm, ((1, 1), (0, 0)), mode="edge")
+    trough = (cm < pad[:-2]) & (cm <= pad[2:])
+    trough[0, :] = cm[0, :] < cm[1, :]
+    ok = trough & (cm < trough_threshold)
+    period = np.argmax(ok, axis=0)
+    none = np.all(~ok, axis=0)
+    period[none] = np.argmin(cm, axis=0)[none]
+    period = min_period + period + np.take_along_axis(shifts, period[None, :], axis=0)[0]
+    return sr / period

@@ -205,3 +205,25 @@ def test_mdx_stft_istft_assemble(hip_ctx, song):
         hip_ctx.to_device(np.array([r[3] for r in ranges], np.int64)), hip_ctx.to_device(np.array(base, np.int32)))
     assert np.array_equal(v.cpu().numpy(), ref_v)
     assert np.array_equal(i.cpu().numpy(), ref_i)
+
+
+def test_yin_f0_autocorrelation_kernel(hip_ctx):
+    """`ac_yin_f0` (librosa.yin = the deterministic stage of the pyin call at pure_vocal_pause_detector.py:422-428)."""
+    t = np.arange(SR * 3) / SR
+    rng = np.random.default_rng(3)
+    f_inst = 180.0 * (1.0 + 0.3 * np.sin(2 * np.pi * 0.4 * t))
+    phase = 2 * np.pi * np.cumsum(f_inst) / SR
+    voiced = sum((0.4 / h) * np.sin(h * phase) for h in range(1, 6))
+    x = (voiced * (np.sin(2 * np.pi * 0.5 * t) > -0.5) + 0.002 * rng.standard_normal(len(t))).astype(np.float32)
+    fmin, fmax = 65.40639132514966, 2093.004522404789          # librosa.note_to_hz('C2'), ('C7')
+    f0, cmnd = hip_ctx.yin_f0(hip_ctx.to_device(x), SR, fmin, fmax, frame_length=2048, hop=441, want_cmnd=True)
+    ref_cm, mn, mx = L.cmnd_frames(x, SR, fmin, fmax, 2048, 441)
+    ref_f0 = L.yin(x, fmin, fmax, sr=SR, frame_length=2048, hop_length=441)
+    assert f0.shape == ref_f0.shape and cmnd.shape == ref_cm.T.shape
+    np.testing.assert_allclose(cmnd.cpu().numpy(), ref_cm.T, rtol=2e-3, atol=2e-4)   # librosa's own float32 FFT noise floor
+    strong = ref_cm.min(axis=0) < 0.05                     # clearly periodic frames: the trough is well defined
+    assert strong.sum() > 100
+    np.testing.assert_allclose(f0[strong], ref_f0[strong], rtol=1e-4)
+    assert np.mean(np.abs(f0 - ref_f0) / ref_f0 < 1e-3) > 0.97      # elsewhere the pick can hop between near-equal troughs
+    sil, _ = hip_ctx.yin_f0(hip_ctx.to_device(np.zeros(8192, np.float32)), SR, fmin, fmax, 2048, 441)
+    assert np.all(sil == SR / 21.0)                        # silent frames: cmnd == 0 everywhere -> first lag, as librosa
