@@ -74,6 +74,9 @@ SIGNATURES = {
     "ac_bias_relu_mul_inplace": (C.c_int, [_P, _P, _P, _P, _I64, _I, _I64, _P]),
     "ac_affine_relu_inplace": (C.c_int, [_P, _P, _P, _P, _I64, _I, _I64, _P]),
     "ac_affine_relu_add": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I, _I64, _P]),
+    "ac_space_to_depth2x": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ac_depth_to_space2x_bias_relu_mul": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -119,6 +122,8 @@ class Context:
         with torch.cuda.device(self.index):
             _check(self.lib.ac_ctx_create(self.index, C.byref(handle)))
         self._h = handle
+        # 3x3 convs of the U-Net: "f16x3" = ac_conv3x3_f16x3 (f16 MFMA, 3-term hi/lo split), "miopen" = PyTorch/MIOpen float32
+        self.conv_impl = os.environ.get("AUDIOCUT_CONV_IMPL", "f16x3")
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -323,6 +328,35 @@ class Context:
         self._nchw(residual)
         out = y if out is None else out
         _check(self.lib.ac_affine_relu_add(self._h, _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), rows, c, inner, _stream()))
+        return out
+
+    def space_to_depth2x(self, x: torch.Tensor) -> torch.Tensor:
+        b, c, h, w = x.shape
+        self._nchw(x)
+        out = torch.empty((b, 4 * c, h // 2, w // 2), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_space_to_depth2x(self._h, _ptr(x), _ptr(out), b, c, h, w, _stream()))
+        return out
+
+    def depth_to_space2x_bias_relu_mul(self, y4: torch.Tensor, bias: torch.Tensor, skip: Optional[torch.Tensor]) -> torch.Tensor:
+        b, c4, h, w = y4.shape
+        self._nchw(y4)
+        c = c4 // 4
+        out = torch.empty((b, c, 2 * h, 2 * w), dtype=torch.float32, device=self.device)
+        if skip is not None and (tuple(skip.shape) != tuple(out.shape) or not skip.is_contiguous()):
+            raise NativeError("skip tensor shape mismatch")
+        _check(self.lib.ac_depth_to_space2x_bias_relu_mul(self._h, _ptr(y4), _ptr(bias), _ptr(skip), _ptr(out), b, c, h, w, _stream()))
+        return out
+
+    def conv3x3_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
+                      relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """3x3 / stride 1 / pad 1 conv on the f16 matrix cores (3-term hi/lo split), fused bias (+ReLU).  NCHW float32."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("conv3x3_f16x3 expects a contiguous float32 NCHW tensor")
+        b, c_in, h, w = x.shape
+        if out is None:
+            out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_conv3x3_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
+                                         float(w_unscale), int(relu), _stream()))
         return out
 
     def mean_square(self, x: torch.Tensor) -> float:

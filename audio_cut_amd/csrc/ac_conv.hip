@@ -1,0 +1,184 @@
+// 3x3 convolution (stride 1, pad 1, NCHW float32 in/out) on the 16-bit matrix cores with a 3-term split:
+//   x = xh + xl, w = wh + wl (float16 pairs; xh = f16(x), xl = f16(x - xh): 22 mantissa bits together)
+//   x*w ~= xh*wh + xh*wl + xl*wh, every f16 x f16 product exact in the float32 accumulator of
+//   v_mfma_f32_16x16x32_f16; the dropped xl*wl term is ~2^-22 relative.
+// That is float32-class accuracy (measured per conv: ~3e-7 of peak against float64, like MIOpen's float32 conv)
+// at the 16-bit MFMA rate, which on gfx950 is 16x the f32 MFMA rate — 3 products still leave 5.3x headroom.
+// Ranges: weights are pre-scaled on the host by a power of two (undone exactly in the epilogue) so their low
+// parts stay normal; activations are saturated to +-65504 (the f16 range; U-Net activations are O(1..1e3)) and
+// their representation error is bounded by max(2^-22 |x|, 3e-8).
+//
+// Implicit GEMM, D[co][pixel] = sum_k A[co][k] B[k][pixel]:  A = weights (M = 48 output channels per workgroup,
+// pre-packed on the host in MFMA fragment order), B = activations (N = an 8 x 32 pixel tile, 4 waves x 64 pixels).
+// K is walked in blocks of 16 input channels; inside a block the 9 taps are paired into 5 k-steps of 32
+// (lane groups 0-1 carry tap 2p, groups 2-3 tap 2p+1; the 10th slot has zero weights).  Per block the
+// (8+2) x (32+2) x 16 input patch is converted to f16 hi/lo once and staged in LDS as [pixel][channel].
+// Epilogue: + bias, optional ReLU, float32 NCHW stores (64-byte segments per output channel).
+#include "ac_common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CV_TH 8
+#define CV_TW 32
+#define CV_PH (CV_TH + 2)
+#define CV_PW (CV_TW + 2)
+#define CV_CB 16                 // input channels per LDS stage
+#define CV_PIX_STRIDE 24         // bf16 elements per pixel row in LDS (16 used + 8 pad -> 48-byte stride)
+#define CV_COB 48                // output channels per workgroup (3 MFMA row tiles)
+#define CV_MT 3
+
+__device__ inline unsigned short f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+
+#define CV_ACT_ITERS ((CV_PH * CV_PW * (CV_CB / 4) + 255) / 256)          // 6: channel-quads of patch pixels per thread
+#define CV_WFRAGS (5 * 2 * CV_MT * 64)                                     // 1920 16-byte weight fragments per stage
+#define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int C_in, int C_out, int H, int W, float w_unscale) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_hi[CV_PH * CV_PW * CV_PIX_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short s_lo[CV_PH * CV_PW * CV_PIX_STRIDE];
+    __shared__ f16x8 s_w[CV_WFRAGS];                       // this stage's weight fragments, shared by the 4 waves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_cob = C_out / CV_COB;
+    const int b = blockIdx.z / n_cob, cob = blockIdx.z % n_cob;
+    const int y0 = blockIdx.y * CV_TH, x0 = blockIdx.x * CV_TW;
+    const int n_cb = C_in / CV_CB;
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * C_in * plane;
+
+    f32x4 acc[CV_MT][4];
+#pragma unroll
+    for (int m = 0; m < CV_MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, px = lane & 15;
+    const int ci_off = 8 * (g & 1);
+    const f16x8* wbase = wpk + (size_t)cob * n_cb * CV_WFRAGS;
+
+    // per-thread staging coordinates (fixed across stages)
+    int a_off[CV_ACT_ITERS];                // LDS element offset, -1 = no work
+    int a_src[CV_ACT_ITERS];                // pixel offset inside the plane, -1 = outside the image (zero padding)
+    int a_c4[CV_ACT_ITERS];
+#pragma unroll
+    for (int i = 0; i < CV_ACT_ITERS; ++i) {
+        const int e = tid + 256 * i;
+        if (e < CV_PH * CV_PW * (CV_CB / 4)) {
+            const int c4 = e / (CV_PH * CV_PW);
+            const int p = e - c4 * (CV_PH * CV_PW);
+            const int py = p / CV_PW, pxx = p - py * CV_PW;
+            const int gy = y0 + py - 1, gx = x0 + pxx - 1;
+            a_off[i] = p * CV_PIX_STRIDE + c4 * 4;
+            a_c4[i] = c4;
+            a_src[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+        } else {
+            a_off[i] = -1; a_src[i] = -1; a_c4[i] = 0;
+        }
+    }
+    float pre_x[CV_ACT_ITERS][4];
+    f16x8 pre_w[CV_W_ITERS];
+
+    auto prefetch = [&](int cb) {
+        const f16x8* wcb = wbase + (size_t)cb * CV_WFRAGS;
+#pragma unroll
+        for (int i = 0; i < CV_W_ITERS; ++i) {
+            const int e = tid + 256 * i;
+            if (e < CV_WFRAGS) pre_w[i] = wcb[e];
+        }
+#pragma unroll
+        for (int i = 0; i < CV_ACT_ITERS; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ci = cb * CV_CB + a_c4[i] * 4 + q;
+                pre_x[i][q] = (a_src[i] >= 0) ? xb[(size_t)ci * plane + a_src[i]] : 0.f;
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int cb = 0; cb < n_cb; ++cb) {
+        __syncthreads();                 // previous stage fully consumed
+#pragma unroll
+        for (int i = 0; i < CV_W_ITERS; ++i) {
+            const int e = tid + 256 * i;
+            if (e < CV_WFRAGS) s_w[e] = pre_w[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CV_ACT_ITERS; ++i) {
+            if (a_off[i] < 0) continue;
+            unsigned short h4[4], l4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = fminf(fmaxf(pre_x[i][q], -65504.f), 65504.f);
+                const _Float16 hv = (_Float16)v;               // v_cvt_f16_f32, round to nearest even
+                h4[q] = f16_bits(hv);
+                l4[q] = f16_bits((_Float16)(v - (float)hv));
+            }
+            *reinterpret_cast<uint2*>(&s_hi[a_off[i]]) = make_uint2((unsigned)h4[0] | ((unsigned)h4[1] << 16), (unsigned)h4[2] | ((unsigned)h4[3] << 16));
+            *reinterpret_cast<uint2*>(&s_lo[a_off[i]]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
+        }
+        __syncthreads();
+        if (cb + 1 < n_cb) prefetch(cb + 1);   // global loads of the next stage fly under this stage's MFMAs
+#pragma unroll
+        for (int pair = 0; pair < 5; ++pair) {
+            int tap = pair * 2 + (g >> 1);
+            if (tap > 8) tap = 8;                          // padded slot: weights are zero, any finite B will do
+            const int dy = tap / 3, dx = tap - dy * 3;
+            f16x8 ah[CV_MT], al[CV_MT];
+#pragma unroll
+            for (int m = 0; m < CV_MT; ++m) {
+                ah[m] = s_w[((pair * 2 + 0) * CV_MT + m) * 64 + lane];
+                al[m] = s_w[((pair * 2 + 1) * CV_MT + m) * 64 + lane];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+                const int off = ((ty + dy) * CV_PW + (tx + dx)) * CV_PIX_STRIDE + ci_off;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+#pragma unroll
+                for (int m = 0; m < CV_MT; ++m) {
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15]
+    float* ob = out + ((size_t)b * C_out + (size_t)cob * CV_COB) * plane;
+#pragma unroll
+    for (int m = 0; m < CV_MT; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y0 + 2 * wave + (q >> 1), xx = x0 + (q & 1) * 16 + px;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m * 16 + g * 4 + r;
+                float v = acc[m][q][r] * w_unscale + bias[cob * CV_COB + co];
+                if (RELU) v = fmaxf(v, 0.f);
+                ob[(size_t)co * plane + (size_t)yy * W + xx] = v;
+            }
+        }
+    }
+}
+
+extern "C" int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                                 int C_out, int H, int W, float w_unscale, int relu, void* stream) {
+    AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
+    AC_REQUIRE(B > 0 && C_in > 0 && C_in % CV_CB == 0 && C_out > 0 && C_out % CV_COB == 0, "C_in % 16 == 0 and C_out % 48 == 0");
+    AC_REQUIRE(H > 0 && H % CV_TH == 0 && W > 0 && W % CV_TW == 0, "H % 8 == 0 and W % 32 == 0");
+    AC_REQUIRE((long long)H * W < (1LL << 31), "plane too large");
+    const long long gz = (long long)B * (C_out / CV_COB);
+    AC_REQUIRE(gz <= 65535 && H / CV_TH <= 65535, "grid too large");
+    dim3 grid(W / CV_TW, H / CV_TH, (unsigned)gz), block(256);
+    if (relu)
+        hipLaunchKernelGGL(k_conv3x3_f16x3<true>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale);
+    else
+        hipLaunchKernelGGL(k_conv3x3_f16x3<false>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

@@ -1,0 +1,56 @@
+"""Host-side packing of 3x3 conv weights for `ac_conv3x3_f16x3` (csrc/ac_conv.hip).
+
+float32 weights [C_out, C_in, 3, 3] (BatchNorm already folded) are scaled by a power of two (so that the low
+halves stay in the normal float16 range; the kernel multiplies the accumulator by the exact inverse), split
+into float16 hi/lo parts (hi = f16(w), lo = f16(w - hi), round-to-nearest-even) and laid out in the A-operand
+fragment order of `v_mfma_f32_16x16x32_f16`: lane l holds A[row = l & 15][k = 8 (l >> 4) + j], j = 0..7.
+K walks blocks of 16 input channels; inside a block the 9 taps are paired into 5 k-steps (lane groups 0-1:
+tap 2p, groups 2-3: tap 2p+1, the 10th slot is zero).
+Result: (uint16 array [C_out/48][C_in/16][5][2 (hi, lo)][3 (row tiles)][64 lanes][8], w_unscale).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+
+def split_hi_lo(w: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    hi = w.astype(np.float16)
+    lo = (w - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def weight_scale(weight: np.ndarray, target: float = 1024.0) -> float:
+    """power of two s with max|w| * s <= target (keeps hi far from the f16 limit and lo out of the subnormals)."""
+    m = float(np.max(np.abs(weight))) if weight.size else 0.0
+    if not np.isfinite(m) or m <= 0.0:
+        return 1.0
+    return float(2.0 ** np.floor(np.log2(target / m)))
+
+
+def pack_conv3x3(weight: np.ndarray) -> Tuple[np.ndarray, float]:
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or co % 48 or ci % 16:
+        raise ValueError("pack_conv3x3 needs [C_out % 48 == 0, C_in % 16 == 0, 3, 3]")
+    scale = weight_scale(weight)
+    hi, lo = split_hi_lo(np.asarray(weight, dtype=np.float32) * np.float32(scale))
+    taps = np.zeros((2, co, ci, 10), dtype=np.uint16)               # tap 9 = zero padding slot
+    taps[0, :, :, :9] = hi.view(np.uint16).reshape(co, ci, 9)
+    taps[1, :, :, :9] = lo.view(np.uint16).reshape(co, ci, 9)
+    lane = np.arange(64)
+    r = lane & 15
+    g = lane >> 4
+    j = np.arange(8)
+    out = np.empty((co // 48, ci // 16, 5, 2, 3, 64, 8), dtype=np.uint16)
+    for cob in range(co // 48):
+        for mt in range(3):
+            rows = cob * 48 + mt * 16 + r                                        # [64]
+            for cb in range(ci // 16):
+                cols = cb * 16 + 8 * (g & 1)[:, None] + j[None, :]               # [64, 8]
+                for pair in range(5):
+                    tap = pair * 2 + (g >> 1)                                    # [64]
+                    for part in range(2):
+                        out[cob, cb, pair, part, mt] = taps[part, rows[:, None], cols, tap[:, None]]
+    return out, 1.0 / scale

@@ -253,19 +253,38 @@ class _Block(nn.Module):
             self.register_buffer(f"ls{j}", torch.from_numpy(s.astype(np.float32)).view(1, -1, 1, 1))
             self.register_buffer(f"lb{j}", torch.from_numpy(sh.astype(np.float32)).view(1, -1, 1, 1))
 
+    def pack_for_hip(self) -> None:
+        """f16 hi/lo fragment-ordered copies of the folded 3x3 weights for ac_conv3x3_f16x3."""
+        from .conv_pack import pack_conv3x3
+        self._w_unscale = []
+        for j in range(self.l):
+            w = getattr(self, f"cw{j}").detach().cpu().numpy()
+            packed, unscale = pack_conv3x3(w)
+            self._w_unscale.append(unscale)
+            self.register_buffer(f"cwp{j}", torch.from_numpy(packed.view(np.int16)).to(getattr(self, f"cw{j}").device))
+
+    def _conv(self, x: torch.Tensor, j: int, hip, probe):
+        """3x3 conv + bias + ReLU.  `hip.conv_impl == "f16x3"`: one fused HIP kernel on the f16 matrix cores (3-term
+        hi/lo split, float32-class accuracy); otherwise MIOpen's float32 conv + the fused bias+ReLU epilogue."""
+        use_mfma = getattr(hip, "conv_impl", "f16x3") == "f16x3" and hasattr(self, f"cwp{j}") \
+            and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
+        if probe is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if use_mfma:
+            y = hip.conv3x3_f16x3(x, getattr(self, f"cwp{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
+        else:
+            y = F.conv2d(x, getattr(self, f"cw{j}"), None, padding=self.pad)
+        if probe is not None:
+            e1.record()
+            probe.append((e0, e1, 2.0 * x.shape[0] * x.shape[1] * x.shape[1] * 9 * x.shape[2] * x.shape[3]))
+        return y if use_mfma else hip.bias_relu_(y, getattr(self, f"cb{j}"))
+
     def forward(self, x: torch.Tensor, hip=None, probe=None) -> torch.Tensor:
         if hip is not None:
             # dense contractions in MIOpen / rocBLAS, every elementwise hop as ONE fused HIP pass (ac_epilogue.hip)
             for j in range(self.l):
-                if probe is not None:
-                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    y = F.conv2d(x, getattr(self, f"cw{j}"), None, padding=self.pad)
-                    e1.record()
-                    probe.append((e0, e1, 2.0 * x.shape[0] * x.shape[1] * x.shape[1] * 9 * x.shape[2] * x.shape[3]))
-                else:
-                    y = F.conv2d(x, getattr(self, f"cw{j}"), None, padding=self.pad)
-                x = hip.bias_relu_(y, getattr(self, f"cb{j}"))
+                x = self._conv(x, j, hip, probe)
             y = hip.affine_relu_(F.linear(x, self.lw0), self.ls0.view(-1), self.lb0.view(-1))
             y = F.linear(y, self.lw1)
             return hip.affine_relu_add(y, self.ls1.view(-1), self.lb1.view(-1), x)
@@ -300,8 +319,34 @@ class TfcTdfNet(nn.Module):
             wf, bf = _fold(w[f"us.{i}.conv.weight"], w[f"us.{i}.conv.bias"], w, f"us.{i}.bn", spec.bn_eps, 1)
             self.register_buffer(f"us_w{i}", torch.from_numpy(wf))
             self.register_buffer(f"us_b{i}", torch.from_numpy(bf))
+            # GEMM forms: down W[co, (tap, ci)], up W[(tap, co), ci] with tap = dy*2 + dx
+            dsw = getattr(self, f"ds_w{i}")                                    # [co, ci, 2, 2]
+            self.register_buffer(f"ds_m{i}", dsw.permute(0, 2, 3, 1).reshape(dsw.shape[0], -1).contiguous())
+            usw = torch.from_numpy(wf)                                         # [ci, co, 2, 2]
+            self.register_buffer(f"us_m{i}", usw.permute(2, 3, 1, 0).reshape(-1, usw.shape[0]).contiguous())
+        if hip is not None:
+            for blk in [*self.enc, *self.dec, self.bottleneck]:
+                blk.pack_for_hip()
         self.register_buffer("final_w", torch.from_numpy(np.ascontiguousarray(w["final_conv.weight"])))
         self.register_buffer("final_b", torch.from_numpy(np.ascontiguousarray(w["final_conv.bias"])))
+
+    def _down(self, x: torch.Tensor, i: int, hip) -> torch.Tensor:
+        """2x2 / stride-2 conv + bias + ReLU = space-to-depth gather (HIP) + one [C', 4C] GEMM (rocBLAS) + fused epilogue."""
+        b, c, h, w = x.shape
+        if getattr(hip, "resample_impl", "gemm") != "gemm" or h % 2 or w % 4:
+            return hip.bias_relu_(F.conv2d(x, getattr(self, f"ds_w{i}"), None, stride=2), getattr(self, f"ds_b{i}"))
+        x2 = hip.space_to_depth2x(x).view(b, 4 * c, (h // 2) * (w // 2))
+        y = torch.matmul(getattr(self, f"ds_m{i}"), x2).view(b, -1, h // 2, w // 2)
+        return hip.bias_relu_(y, getattr(self, f"ds_b{i}"))
+
+    def _up(self, x: torch.Tensor, i: int, hip, skip: torch.Tensor) -> torch.Tensor:
+        """2x2 / stride-2 transposed conv + bias + ReLU + multiplicative skip = one [4C', C] GEMM + one scatter pass."""
+        b, c, h, w = x.shape
+        if getattr(hip, "resample_impl", "gemm") != "gemm" or w % 2:
+            y = F.conv_transpose2d(x, getattr(self, f"us_w{i}"), None, stride=2)
+            return hip.bias_relu_mul_(y, getattr(self, f"us_b{i}"), skip)
+        y4 = torch.matmul(getattr(self, f"us_m{i}"), x.view(b, c, h * w)).view(b, -1, h, w)
+        return hip.depth_to_space2x_bias_relu_mul(y4, getattr(self, f"us_b{i}"), skip)
 
     @torch.no_grad()
     def forward(self, spec_in: torch.Tensor) -> torch.Tensor:
@@ -321,11 +366,10 @@ class TfcTdfNet(nn.Module):
             for i in range(n):
                 x = self.enc[i](x, hip, self.conv_probe)
                 skips.append(x)
-                x = hip.bias_relu_(F.conv2d(x, getattr(self, f"ds_w{i}"), None, stride=2), getattr(self, f"ds_b{i}"))
+                x = self._down(x, i, hip)
             x = self.bottleneck(x, hip, self.conv_probe)
             for i in range(n):
-                x = F.conv_transpose2d(x, getattr(self, f"us_w{i}"), None, stride=2)
-                x = hip.bias_relu_mul_(x, getattr(self, f"us_b{i}"), skips.pop())
+                x = self._up(x, i, hip, skips.pop())
                 x = self.dec[i](x, hip, self.conv_probe)
             return F.conv2d(x, self.final_w, self.final_b)
         x = F.relu_(F.conv2d(spec_tf, self.first_w, self.first_b))

@@ -175,6 +175,25 @@ int ac_affine_relu_inplace(ac_ctx* ctx, float* x, const float* scale, const floa
 int ac_affine_relu_add(ac_ctx* ctx, const float* y, const float* scale, const float* shift, const float* residual,
                        float* out, int64_t rows, int C, int64_t inner, void* stream);
 
+/* The 2x2 / stride-2 down- and up-sampling convolutions of the same graph as plain GEMMs plus one streaming pass:
+ *   ac_space_to_depth2x:               x [B][C][H][W] -> out [B][4][C][H/2][W/2] (tap = dy*2 + dx); a [C', 4C] GEMM
+ *                                      and ac_bias_relu_inplace then give relu(conv2x2_s2(x) + b)
+ *   ac_depth_to_space2x_bias_relu_mul: y4 [B][4][C][H][W] (a [4C, C_in] GEMM of the input) ->
+ *                                      out [B][C][2H][2W] = relu(y4[tap] + bias[c]) * skip (skip may be NULL) */
+int ac_space_to_depth2x(ac_ctx* ctx, const float* x, float* out, int B, int C, int H, int W, void* stream);
+int ac_depth_to_space2x_bias_relu_mul(ac_ctx* ctx, const float* y4, const float* bias, const float* skip, float* out,
+                                      int B, int C, int H, int W, void* stream);
+
+/* 3x3 convolution (stride 1, pad 1) of the U-Net, NCHW float32 in/out, on the 16-bit matrix cores with a 3-term
+ * float16 hi/lo split (x*w ~= xh*wh + xh*wl + xl*wh; products exact in the float32 MFMA accumulator): float32-class
+ * accuracy (~3e-7 of peak per conv) at the f16 MFMA rate.  Replaces the Conv nodes of the graph run at
+ * separation/backends.py:358.  w_packed = weights (BatchNorm folded, scaled by a power of two 1/w_unscale)
+ * pre-arranged in MFMA fragment order by audio_cut_amd.separation.conv_pack.pack_conv3x3
+ * ([C_out/48][C_in/16][5][hi,lo][3][64] fragments of 8 f16).  C_in % 16 == 0, C_out % 48 == 0, H % 8 == 0,
+ * W % 32 == 0.  out = conv(x) * w_unscale + bias[c], followed by ReLU when relu != 0. */
+int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                     int C_out, int H, int W, float w_unscale, int relu, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score
