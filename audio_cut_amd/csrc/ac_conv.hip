@@ -30,17 +30,24 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ inline unsigned short f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
-#define CV_ACT_ITERS ((CV_PH * CV_PW * (CV_CB / 4) + 255) / 256)          // 6: channel-quads of patch pixels per thread
+// staging work items: (row 0..9, aligned column quad 0..9 covering x0-4 .. x0+35, channel quad 0..3)
+#define CV_QUADS 10
+#define CV_ITEMS (CV_PH * CV_QUADS * (CV_CB / 4))                          // 400
+#define CV_ACT_ITERS ((CV_ITEMS + 255) / 256)                              // 2
 #define CV_WFRAGS (5 * 2 * CV_MT * 64)                                     // 1920 16-byte weight fragments per stage
 #define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
+#define CV_OUT_STRIDE (CV_TW + 4)                                          // floats per (co, row) line of the output staging
 
 template <bool RELU>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int C_in, int C_out, int H, int W, float w_unscale) {
-    __shared__ __attribute__((aligned(16))) unsigned short s_hi[CV_PH * CV_PW * CV_PIX_STRIDE];
-    __shared__ __attribute__((aligned(16))) unsigned short s_lo[CV_PH * CV_PW * CV_PIX_STRIDE];
-    __shared__ f16x8 s_w[CV_WFRAGS];                       // this stage's weight fragments, shared by the 4 waves
+    // one LDS arena: [hi patch | lo patch | weight fragments] during the K loop, re-used as the output staging tile
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * CV_PH * CV_PW * CV_PIX_STRIDE * 2 + CV_WFRAGS * 16];
+    unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
+    unsigned short* s_lo = s_hi + CV_PH * CV_PW * CV_PIX_STRIDE;
+    f16x8* s_w = reinterpret_cast<f16x8*>(s_raw + 2 * CV_PH * CV_PW * CV_PIX_STRIDE * 2);
+    float* s_out = reinterpret_cast<float*>(s_raw);       // [48 co][8 rows][CV_OUT_STRIDE] = 55296 B <= arena (63360 B)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_cob = C_out / CV_COB;
     const int b = blockIdx.z / n_cob, cob = blockIdx.z % n_cob;
@@ -59,26 +66,28 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     const int ci_off = 8 * (g & 1);
     const f16x8* wbase = wpk + (size_t)cob * n_cb * CV_WFRAGS;
 
-    // per-thread staging coordinates (fixed across stages)
-    int a_off[CV_ACT_ITERS];                // LDS element offset, -1 = no work
-    int a_src[CV_ACT_ITERS];                // pixel offset inside the plane, -1 = outside the image (zero padding)
+    // per-thread staging coordinates (fixed across stages): one aligned float4 of 4 channels each
+    int a_src[CV_ACT_ITERS];                // float offset inside the plane of the float4, -1 = outside the image (zeros)
+    int a_pix[CV_ACT_ITERS];                // patch pixel index of the float4's first column (may be < row start: clipped)
+    int a_col[CV_ACT_ITERS];                // patch column of the first element (-3 .. 33)
     int a_c4[CV_ACT_ITERS];
 #pragma unroll
     for (int i = 0; i < CV_ACT_ITERS; ++i) {
         const int e = tid + 256 * i;
-        if (e < CV_PH * CV_PW * (CV_CB / 4)) {
-            const int c4 = e / (CV_PH * CV_PW);
-            const int p = e - c4 * (CV_PH * CV_PW);
-            const int py = p / CV_PW, pxx = p - py * CV_PW;
-            const int gy = y0 + py - 1, gx = x0 + pxx - 1;
-            a_off[i] = p * CV_PIX_STRIDE + c4 * 4;
+        if (e < CV_ITEMS) {
+            const int c4 = e / (CV_PH * CV_QUADS);
+            const int r = e - c4 * (CV_PH * CV_QUADS);
+            const int py = r / CV_QUADS, qd = r - py * CV_QUADS;
+            const int gy = y0 + py - 1, gx = x0 - 4 + 4 * qd;          // aligned: x0 % 32 == 0
             a_c4[i] = c4;
+            a_col[i] = 4 * qd - 3;                                     // patch column = gx - (x0 - 1)
+            a_pix[i] = py * CV_PW;
             a_src[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
         } else {
-            a_off[i] = -1; a_src[i] = -1; a_c4[i] = 0;
+            a_c4[i] = -1; a_col[i] = 0; a_pix[i] = 0; a_src[i] = -1;
         }
     }
-    float pre_x[CV_ACT_ITERS][4];
+    float4 pre_x[CV_ACT_ITERS][4];
     f16x8 pre_w[CV_W_ITERS];
 
     auto prefetch = [&](int cb) {
@@ -92,8 +101,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ci = cb * CV_CB + a_c4[i] * 4 + q;
-                pre_x[i][q] = (a_src[i] >= 0) ? xb[(size_t)ci * plane + a_src[i]] : 0.f;
+                const int ci = cb * CV_CB + (a_c4[i] < 0 ? 0 : a_c4[i]) * 4 + q;
+                pre_x[i][q] = (a_src[i] >= 0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_src[i])
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -108,17 +118,24 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         }
 #pragma unroll
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
-            if (a_off[i] < 0) continue;
-            unsigned short h4[4], l4[4];
+            if (a_c4[i] < 0) continue;
+            const float* v4[4] = {&pre_x[i][0].x, &pre_x[i][1].x, &pre_x[i][2].x, &pre_x[i][3].x};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v = fminf(fmaxf(pre_x[i][q], -65504.f), 65504.f);
-                const _Float16 hv = (_Float16)v;               // v_cvt_f16_f32, round to nearest even
-                h4[q] = f16_bits(hv);
-                l4[q] = f16_bits((_Float16)(v - (float)hv));
+            for (int k = 0; k < 4; ++k) {                              // 4 pixels of the float4
+                const int col = a_col[i] + k;
+                if (col < 0 || col >= CV_PW) continue;                 // the 6 alignment columns outside the patch
+                unsigned short h4[4], l4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fminf(fmaxf(v4[q][k], -65504.f), 65504.f);
+                    const _Float16 hv = (_Float16)v;                   // v_cvt_f16_f32, round to nearest even
+                    h4[q] = f16_bits(hv);
+                    l4[q] = f16_bits((_Float16)(v - (float)hv));
+                }
+                const int off = (a_pix[i] + col) * CV_PIX_STRIDE + a_c4[i] * 4;
+                *reinterpret_cast<uint2*>(&s_hi[off]) = make_uint2((unsigned)h4[0] | ((unsigned)h4[1] << 16), (unsigned)h4[2] | ((unsigned)h4[3] << 16));
+                *reinterpret_cast<uint2*>(&s_lo[off]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
             }
-            *reinterpret_cast<uint2*>(&s_hi[a_off[i]]) = make_uint2((unsigned)h4[0] | ((unsigned)h4[1] << 16), (unsigned)h4[2] | ((unsigned)h4[3] << 16));
-            *reinterpret_cast<uint2*>(&s_lo[a_off[i]]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
         }
         __syncthreads();
         if (cb + 1 < n_cb) prefetch(cb + 1);   // global loads of the next stage fly under this stage's MFMAs
@@ -148,21 +165,30 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
             }
         }
     }
-    // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15]
-    float* ob = out + ((size_t)b * C_out + (size_t)cob * CV_COB) * plane;
+    // ---- epilogue: accumulators (D[row = (lane>>4)*4 + r][col = lane&15]) -> LDS tile [co][row][x] -> 128-byte row stores
+    __syncthreads();                     // all waves done with the stage buffers
 #pragma unroll
     for (int m = 0; m < CV_MT; ++m) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int yy = y0 + 2 * wave + (q >> 1), xx = x0 + (q & 1) * 16 + px;
+            const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = m * 16 + g * 4 + r;
                 float v = acc[m][q][r] * w_unscale + bias[cob * CV_COB + co];
                 if (RELU) v = fmaxf(v, 0.f);
-                ob[(size_t)co * plane + (size_t)yy * W + xx] = v;
+                s_out[(co * CV_TH + ty) * CV_OUT_STRIDE + tx] = v;
             }
         }
+    }
+    __syncthreads();
+    float* ob = out + ((size_t)b * C_out + (size_t)cob * CV_COB) * plane;
+    // 48 co x 8 rows x 8 float4 = 3072 float4 over 256 threads: 8 consecutive threads write one 128-byte row segment
+    for (int e = tid; e < CV_COB * CV_TH * (CV_TW / 4); e += 256) {
+        const int line = e >> 3, q4 = e & 7;
+        const int co = line >> 3, ty = line & 7;
+        const float4 v = *reinterpret_cast<const float4*>(&s_out[line * CV_OUT_STRIDE + 4 * q4]);
+        *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
     }
 }
 
