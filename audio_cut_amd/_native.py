@@ -77,6 +77,7 @@ SIGNATURES = {
     "ac_space_to_depth2x": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_depth_to_space2x_bias_relu_mul": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
+    "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -124,6 +125,8 @@ class Context:
         self._h = handle
         # 3x3 convs of the U-Net: "f16x3" = ac_conv3x3_f16x3 (f16 MFMA, 3-term hi/lo split), "miopen" = PyTorch/MIOpen float32
         self.conv_impl = os.environ.get("AUDIOCUT_CONV_IMPL", "f16x3")
+        # TDF layers: "f16x3" = ac_tdf_linear_f16x3 (fused GEMM + affine + ReLU (+ residual)), "rocblas" = float32 rocBLAS + epilogues
+        self.tdf_impl = os.environ.get("AUDIOCUT_TDF_IMPL", "f16x3")
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -357,6 +360,20 @@ class Context:
             out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
         _check(self.lib.ac_conv3x3_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
                                          float(w_unscale), int(relu), _stream()))
+        return out
+
+    def tdf_linear_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, n_out: int, scale: torch.Tensor, shift: torch.Tensor,
+                         w_unscale: float, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """TDF layer on the f16 matrix cores: relu(scale[c] * (x @ W^T) + shift[c]) (+ resid) over the last axis of an
+        NCHW float32 tensor [B, C, T, K] -> [B, C, T, n_out].  Shapes the kernel cannot tile raise NativeError."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("tdf_linear_f16x3 expects a contiguous float32 NCHW tensor")
+        b, c, t, k = x.shape
+        out = torch.empty((b, c, t, n_out), dtype=torch.float32, device=self.device)
+        if resid is not None and (resid.shape != out.shape or not resid.is_contiguous() or resid.dtype != torch.float32):
+            raise NativeError("tdf_linear_f16x3: residual must match the output")
+        _check(self.lib.ac_tdf_linear_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(resid), _ptr(out),
+                                            b * c * t, n_out, k, t, c, float(w_unscale), _stream()))
         return out
 
     def mean_square(self, x: torch.Tensor) -> float:

@@ -82,6 +82,8 @@ extern "C" int ac_ctx_create(int device, ac_ctx** out) {
     ac_ctx* c = (ac_ctx*)calloc(1, sizeof(ac_ctx));
     if (!c) { ac_set_error("out of host memory"); return AC_E_NOMEM; }
     c->device = device;
+    AC_CHECK_HIP(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device));
+    if (c->n_cu <= 0) c->n_cu = 256;
     int rc;
     {
         std::vector<double2> tw(1024);

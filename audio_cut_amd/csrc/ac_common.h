@@ -11,6 +11,7 @@
 
 struct ac_ctx {
     int device;
+    int n_cu;            // compute units of the device (persistent-grid sizing)
     // real-FFT 2048 (float64): tw2048[k] = exp(-2*pi*i*k/2048), k < 1024 ; hann2048 periodic (float64)
     double2* tw2048;
     double* hann2048;

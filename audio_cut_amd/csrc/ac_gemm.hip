@@ -1,0 +1,198 @@
+// TDF (time-distributed fully connected) layers of the TFC-TDF U-Net on the 16-bit matrix cores:
+//   y[m][n] = (resid ? resid[m][n] : 0) + relu(scale[c(m)] * sum_k x[m][k] * w[n][k] + shift[c(m)]),   c(m) = (m / T) % C
+// x is the NCHW activation seen as rows (b, c, t) of F floats, w a bias-free Linear weight [N][K], scale/shift the
+// eval-mode BatchNorm2d over channels that follows it, resid the block's residual input (second TDF layer only).
+// Arithmetic: the same 3-term float16 split as ac_conv.hip (x = xh + xl, w = wh + wl, xh*wh + xh*wl + xl*wh with
+// float32 accumulation in v_mfma_f32_16x16x32_f16) - float32-class products at the 16-bit MFMA rate.
+//
+// Workgroup: 256 threads = 2 x 2 waves, tile 128 rows x (32 * NT) columns, wave tile 64 x (16 * NT) (NT = 6 or 3).
+// K is walked in stages of 32: the x tile is loaded as full 128-byte row segments (float4 per lane), split to f16
+// hi/lo once and staged in LDS as [row][k] with an 80-byte row stride (conflict-free ds_read_b128 A fragments); the
+// weights arrive pre-split and pre-packed in B-fragment order (conv_pack.pack_linear) and are copied through.  The
+// next stage's global loads are issued before the current stage's MFMAs.  Epilogue: accumulators -> per-wave LDS
+// strip -> affine + ReLU (+ residual) -> 384-byte (192-byte for NT = 3) contiguous row stores.
+#include "ac_common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define GM_BM 128
+#define GM_BK 32
+#define GM_ASTRIDE 40            // f16 elements per staged x row (32 used + 8 pad -> 80 bytes)
+#define GM_MT 4                  // 16-row tiles per wave
+#define GM_A_ITERS ((GM_BM * (GM_BK / 4)) / 256)     // float4 loads per thread per stage (4)
+
+__device__ inline unsigned short gm_f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+
+template <int NT, bool RESID>
+__global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ resid, float* __restrict__ y,
+                                                             int n_mblk, int N, int K, int T, int C, float w_unscale) {
+    constexpr int BN = 32 * NT;                       // columns per workgroup
+    constexpr int BFRAGS = 2 * (BN / 16) * 64;        // 16-byte weight fragments per stage (hi, lo)
+    constexpr int B_ITERS = BFRAGS / 256;             // 6 (NT = 6) or 3
+    constexpr int OSTRIDE = 16 * NT + 4;              // floats per row of a wave's output strip
+    constexpr int A_BYTES = 2 * GM_BM * GM_ASTRIDE * 2;
+    constexpr int O_BYTES = 4 * 16 * OSTRIDE * 4;
+    constexpr int ARENA = (A_BYTES + BFRAGS * 16) > O_BYTES ? (A_BYTES + BFRAGS * 16) : O_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[ARENA];
+    unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
+    unsigned short* s_lo = s_hi + GM_BM * GM_ASTRIDE;
+    f16x8* s_b = reinterpret_cast<f16x8*>(s_raw + A_BYTES);
+    float* s_out = reinterpret_cast<float*>(s_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_nblk = N / BN;
+    // XCD-aware work order (see ac_conv.hip): XCD `L & 7` walks a contiguous strip; the column blocks of one row
+    // block are adjacent items, so the x tile crosses the fabric once and the siblings hit L2.
+    int wi = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int nb = wi % n_nblk, mb = wi / n_nblk;
+    if (mb >= n_mblk) return;
+    const size_t m0 = (size_t)mb * GM_BM;
+    const int n0 = nb * BN;
+    const int n_stage = K / GM_BK;
+
+    f32x4 acc[GM_MT][NT];
+#pragma unroll
+    for (int m = 0; m < GM_MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging coordinates: float4 e covers row e >> 3, k-quad e & 7 (8 lanes = one 128-byte row segment)
+    const float* a_ptr[GM_A_ITERS];
+    int a_off[GM_A_ITERS];
+#pragma unroll
+    for (int i = 0; i < GM_A_ITERS; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e >> 3, kq = e & 7;
+        a_ptr[i] = x + (m0 + row) * (size_t)K + 4 * kq;
+        a_off[i] = row * GM_ASTRIDE + 4 * kq;
+    }
+    const f16x8* wbase = wpk + (size_t)nb * n_stage * BFRAGS;
+
+    float4 pre_a[GM_A_ITERS];
+    f16x8 pre_b[B_ITERS];
+    auto prefetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) pre_b[i] = wbase[(size_t)s * BFRAGS + tid + 256 * i];
+#pragma unroll
+        for (int i = 0; i < GM_A_ITERS; ++i) pre_a[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)s * GM_BK);
+    };
+
+    const int frag_row = lane & 15, frag_k = 8 * (lane >> 4);
+    prefetch(0);
+    for (int s = 0; s < n_stage; ++s) {
+        __syncthreads();                 // previous stage fully consumed
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) s_b[tid + 256 * i] = pre_b[i];
+#pragma unroll
+        for (int i = 0; i < GM_A_ITERS; ++i) {
+            const float v[4] = {pre_a[i].x, pre_a[i].y, pre_a[i].z, pre_a[i].w};
+            unsigned short h[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float c = fminf(fmaxf(v[q], -65504.f), 65504.f);
+                const _Float16 hv = (_Float16)c;
+                h[q] = gm_f16_bits(hv);
+                l[q] = gm_f16_bits((_Float16)(c - (float)hv));
+            }
+            *reinterpret_cast<uint2*>(&s_hi[a_off[i]]) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+            *reinterpret_cast<uint2*>(&s_lo[a_off[i]]) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+        }
+        __syncthreads();
+        if (s + 1 < n_stage) prefetch(s + 1);
+        f16x8 ah[GM_MT], al[GM_MT];
+#pragma unroll
+        for (int m = 0; m < GM_MT; ++m) {
+            const int off = (wm * 64 + m * 16 + frag_row) * GM_ASTRIDE + frag_k;
+            ah[m] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+            al[m] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const f16x8 bh = s_b[(0 * (BN / 16) + wn * NT + n) * 64 + lane];
+            const f16x8 bl = s_b[(1 * (BN / 16) + wn * NT + n) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < GM_MT; ++m) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: D[row = (lane >> 4) * 4 + r][col = lane & 15] -> per-wave LDS strip [16 rows][16 NT cols] -> row stores.
+    // The strips are private to a wave and LDS executes a wave's accesses in order, so only the first hand-over (stage
+    // buffers -> strips) needs a workgroup barrier; the residual rows of strip m + 1 are fetched while strip m is written.
+    const int g = lane >> 4, px = lane & 15;
+    float* so = s_out + wave * 16 * OSTRIDE;
+    constexpr int ROW_F4 = 4 * NT;                    // float4 per output row of the wave tile
+    constexpr int E_ITERS = 16 * ROW_F4 / 64;         // float4 per lane per strip (6 or 3)
+    float4 rr[2][E_ITERS];
+    auto out_offset = [&](int m, int i, int& c) -> size_t {
+        const int e = lane + 64 * i;
+        const int row = e / ROW_F4, q4 = e - row * ROW_F4;
+        const size_t gm = m0 + wm * 64 + m * 16 + row;
+        c = (int)((gm / (size_t)T) % (size_t)C);
+        return gm * (size_t)N + n0 + wn * (16 * NT) + 4 * q4;
+    };
+    if (RESID) {
+#pragma unroll
+        for (int i = 0; i < E_ITERS; ++i) { int c; rr[0][i] = *reinterpret_cast<const float4*>(resid + out_offset(0, i, c)); }
+    }
+    __syncthreads();                     // every wave is done reading the stage buffers
+#pragma unroll
+    for (int m = 0; m < GM_MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[(g * 4 + r) * OSTRIDE + n * 16 + px] = acc[m][n][r];
+        if (RESID && m + 1 < GM_MT) {
+#pragma unroll
+            for (int i = 0; i < E_ITERS; ++i) { int c; rr[(m + 1) & 1][i] = *reinterpret_cast<const float4*>(resid + out_offset(m + 1, i, c)); }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < E_ITERS; ++i) {
+            const int e = lane + 64 * i;
+            const int row = e / ROW_F4, q4 = e - row * ROW_F4;
+            int c;
+            const size_t o = out_offset(m, i, c);
+            const float sc = scale[c] * w_unscale, sh = shift[c];
+            float4 v = *reinterpret_cast<const float4*>(&so[row * OSTRIDE + 4 * q4]);
+            v.x = fmaxf(v.x * sc + sh, 0.f); v.y = fmaxf(v.y * sc + sh, 0.f);
+            v.z = fmaxf(v.z * sc + sh, 0.f); v.w = fmaxf(v.w * sc + sh, 0.f);
+            if (RESID) { const float4 q = rr[m & 1][i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            *reinterpret_cast<float4*>(y + o) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
+                                    const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale,
+                                    void* stream) {
+    AC_REQUIRE(ctx && x && w_packed && scale && shift && y, "null pointer");
+    AC_REQUIRE(M > 0 && M % GM_BM == 0, "M % 128 == 0");
+    AC_REQUIRE(K > 0 && K % GM_BK == 0, "K % 32 == 0");
+    AC_REQUIRE(N > 0 && N % 96 == 0, "N % 96 == 0");
+    AC_REQUIRE(T > 0 && C > 0, "T, C > 0");
+    const bool wide = (N % 192) == 0;
+    const long long n_mblk = M / GM_BM;
+    long long nblk = n_mblk * (N / (wide ? 192 : 96));
+    AC_REQUIRE(nblk < (1LL << 31) - 8 && n_mblk < (1LL << 31), "grid too large");
+    dim3 grid((unsigned)nblk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const f16x8* wp = (const f16x8*)w_packed;
+    if (wide) {
+        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<6, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
+        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<6, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
+    } else {
+        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<3, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
+        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<3, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
+    }
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

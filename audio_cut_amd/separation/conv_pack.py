@@ -54,3 +54,26 @@ def pack_conv3x3(weight: np.ndarray) -> Tuple[np.ndarray, float]:
                     for part in range(2):
                         out[cob, cb, pair, part, mt] = taps[part, rows[:, None], cols, tap[:, None]]
     return out, 1.0 / scale
+
+
+def linear_tileable(n_out: int, k_in: int, rows: int) -> bool:
+    """shapes `ac_tdf_linear_f16x3` tiles: rows % 128 == 0, K % 32 == 0, N % 96 == 0."""
+    return rows % 128 == 0 and k_in % 32 == 0 and n_out % 96 == 0
+
+
+def pack_linear(weight: np.ndarray) -> Tuple[np.ndarray, float]:
+    """Linear weight [N, K] (y = x @ W^T) -> B-operand fragments of `v_mfma_f32_16x16x32_f16` for ac_tdf_linear_f16x3:
+    lane l of a fragment holds B[k = 8 (l >> 4) + j][n = l & 15] = W[n0 + (l & 15)][k0 + 8 (l >> 4) + j], j = 0..7.
+    Result: (uint16 [N/BN][K/32][2 (hi, lo)][BN/16][64][8], w_unscale) with BN = 192 when N % 192 == 0, else 96."""
+    n, k = weight.shape
+    if n % 96 or k % 32:
+        raise ValueError("pack_linear needs N % 96 == 0 and K % 32 == 0")
+    bn = 192 if n % 192 == 0 else 96
+    scale = weight_scale(weight)
+    hi, lo = split_hi_lo(np.asarray(weight, dtype=np.float32) * np.float32(scale))
+    parts = np.stack([hi.view(np.uint16), lo.view(np.uint16)])            # [2, N, K]
+    # [2, N/BN, BN/16, 16 (n in tile), K/32, 4 (lane group), 8 (j)]
+    p = parts.reshape(2, n // bn, bn // 16, 16, k // 32, 4, 8)
+    # -> [N/BN, K/32, 2, BN/16, lane = group * 16 + n_in_tile, 8]
+    out = p.transpose(1, 4, 0, 2, 5, 3, 6).reshape(n // bn, k // 32, 2, bn // 16, 64, 8)
+    return np.ascontiguousarray(out), 1.0 / scale

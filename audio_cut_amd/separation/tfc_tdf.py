@@ -255,7 +255,14 @@ class _Block(nn.Module):
 
     def pack_for_hip(self) -> None:
         """f16 hi/lo fragment-ordered copies of the folded 3x3 weights for ac_conv3x3_f16x3."""
-        from .conv_pack import pack_conv3x3
+        from .conv_pack import pack_conv3x3, pack_linear
+        self._l_unscale = [None, None]
+        for j in range(2):
+            w = getattr(self, f"lw{j}").detach().cpu().numpy()
+            if w.shape[0] % 96 == 0 and w.shape[1] % 32 == 0:
+                packed, unscale = pack_linear(w)
+                self._l_unscale[j] = unscale
+                self.register_buffer(f"lwp{j}", torch.from_numpy(packed.view(np.int16)).to(getattr(self, f"lw{j}").device))
         self._w_unscale = []
         for j in range(self.l):
             w = getattr(self, f"cw{j}").detach().cpu().numpy()
@@ -280,14 +287,27 @@ class _Block(nn.Module):
             probe.append((e0, e1, 2.0 * x.shape[0] * x.shape[1] * x.shape[1] * 9 * x.shape[2] * x.shape[3]))
         return y if use_mfma else hip.bias_relu_(y, getattr(self, f"cb{j}"))
 
+    def _tdf(self, x: torch.Tensor, hip) -> torch.Tensor:
+        """x + relu(bn(linear(relu(bn(linear(x)))))) over the frequency axis.  `hip.tdf_impl == "f16x3"`: each layer is one
+        fused HIP kernel on the f16 matrix cores (ac_tdf_linear_f16x3: GEMM + per-channel affine + ReLU (+ residual));
+        shapes it cannot tile (the narrow bottleneck widths of the deep levels) and "rocblas" use rocBLAS float32 GEMMs
+        + the fused epilogue kernels."""
+        rows = x.shape[0] * x.shape[1] * x.shape[2]
+        mfma = getattr(hip, "tdf_impl", "f16x3") == "f16x3" and rows % 128 == 0
+        if mfma and hasattr(self, "lwp0"):
+            y = hip.tdf_linear_f16x3(x, self.lwp0, self.lw0.shape[0], self.ls0.view(-1), self.lb0.view(-1), self._l_unscale[0])
+        else:
+            y = hip.affine_relu_(F.linear(x, self.lw0), self.ls0.view(-1), self.lb0.view(-1))
+        if mfma and hasattr(self, "lwp1"):
+            return hip.tdf_linear_f16x3(y, self.lwp1, self.lw1.shape[0], self.ls1.view(-1), self.lb1.view(-1), self._l_unscale[1], resid=x)
+        return hip.affine_relu_add(F.linear(y, self.lw1), self.ls1.view(-1), self.lb1.view(-1), x)
+
     def forward(self, x: torch.Tensor, hip=None, probe=None) -> torch.Tensor:
         if hip is not None:
             # dense contractions in MIOpen / rocBLAS, every elementwise hop as ONE fused HIP pass (ac_epilogue.hip)
             for j in range(self.l):
                 x = self._conv(x, j, hip, probe)
-            y = hip.affine_relu_(F.linear(x, self.lw0), self.ls0.view(-1), self.lb0.view(-1))
-            y = F.linear(y, self.lw1)
-            return hip.affine_relu_add(y, self.ls1.view(-1), self.lb1.view(-1), x)
+            return self._tdf(x, hip)
         for j in range(self.l):
             x = F.relu_(F.conv2d(x, getattr(self, f"cw{j}"), getattr(self, f"cb{j}"), padding=self.pad))
         y = x

@@ -194,6 +194,16 @@ int ac_depth_to_space2x_bias_relu_mul(ac_ctx* ctx, const float* y4, const float*
 int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                      int C_out, int H, int W, float w_unscale, int relu, void* stream);
 
+/* TDF layer of a TFC-TDF block (bias-free Linear over the frequency axis + eval BatchNorm2d over channels + ReLU;
+ * the MatMul / BatchNormalization / Relu (/ Add) nodes of the graph run at separation/backends.py:358, restated in
+ * oracle/separator.py:_tfc_tdf), same 3-term float16 split as ac_conv3x3_f16x3:
+ *   y[m][n] = (resid ? resid[m][n] : 0) + relu(scale[c] * w_unscale * sum_k x[m][k] w[n][k] + shift[c]),  c = (m / T) % C
+ * x [M][K] float32 (the NCHW activation as rows (b, c, t)), y / resid [M][N]; w_packed from
+ * audio_cut_amd.separation.conv_pack.pack_linear ([N/BN][K/32][hi,lo][BN/16][64] fragments of 8 f16, BN = 192 when
+ * N % 192 == 0 else 96).  M % 128 == 0, K % 32 == 0, N % 96 == 0. */
+int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
+                        const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score

@@ -14,7 +14,7 @@
 // (lane groups 0-1 carry tap 2p, groups 2-3 tap 2p+1; the 10th slot has zero weights).  Per block the
 // (8+2) x (32+2) x 16 input patch is converted to f16 hi/lo once and staged in LDS as [pixel][channel].
 // Epilogue: + bias, optional ReLU, float32 NCHW stores (64-byte segments per output channel).
-#include "../audio_cut_amd/csrc/ac_common.h"
+#include "ac_common.h"
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -30,24 +30,61 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ inline unsigned short f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
-#define CV_ACT_ITERS ((CV_PH * CV_PW * (CV_CB / 4) + 255) / 256)          // 6: channel-quads of patch pixels per thread
+// staging work items: (row 0..9, aligned column quad 0..9 covering x0-4 .. x0+35, channel quad 0..3)
+#define CV_QUADS 10
+#define CV_ITEMS (CV_PH * CV_QUADS * (CV_CB / 4))                          // 400
+#define CV_ACT_ITERS ((CV_ITEMS + 255) / 256)                              // 2
 #define CV_WFRAGS (5 * 2 * CV_MT * 64)                                     // 1920 16-byte weight fragments per stage
 #define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
+#define CV_OUT_STRIDE (CV_TW + 4)                                          // floats per (co, row) line of the output staging
 
+struct cv_tile { int b, cob, y0, x0; };
+
+// work item -> (image, C_out block, tile origin).  The C_out blocks of one pixel tile are adjacent work items (their
+// input patch comes from HBM once, the siblings hit L2) and tiles run down `bw`-wide column bands, so the x and y
+// neighbours whose halos overlap are at most `bw` tiles apart in the walk.
+__device__ inline cv_tile cv_decode(int wi, int n_cob, int tiles_x, int tiles_y, int bw) {
+    cv_tile t;
+    t.cob = wi % n_cob;
+    int r = wi / n_cob;
+    t.b = r / (tiles_x * tiles_y);
+    r -= t.b * (tiles_x * tiles_y);
+    const int band = r / (tiles_y * bw);
+    r -= band * (tiles_y * bw);
+    t.y0 = (r / bw) * CV_TH;
+    t.x0 = (band * bw + r % bw) * CV_TW;
+    return t;
+}
+
+// Persistent workgroups (2 per CU): workgroups are dealt round-robin over the 8 XCDs (L and L+8 share an L2), so the
+// workgroups of XCD `L & 7` walk one contiguous strip of the work list together, item j, j + G, j + 2G ... for the j-th
+// of the G workgroups of that XCD: what runs concurrently on an XCD is a run of neighbouring tiles.  The (tile, channel
+// block) stages of a workgroup form ONE software pipeline: the global loads of stage s+1 are issued before the MFMAs of
+// stage s, across tile boundaries, so a tile's first loads fly under the previous tile's last MFMAs and its stores.
 template <bool RELU>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int C_in, int C_out, int H, int W, float w_unscale, int mode) {
-    __shared__ __attribute__((aligned(16))) unsigned short s_hi[CV_PH * CV_PW * CV_PIX_STRIDE];
-    __shared__ __attribute__((aligned(16))) unsigned short s_lo[CV_PH * CV_PW * CV_PIX_STRIDE];
-    __shared__ f16x8 s_w[CV_WFRAGS];                       // this stage's weight fragments, shared by the 4 waves
+                                                          int C_in, int C_out, int H, int W, float w_unscale, int bw, int n_work, int mode) {
+    // one LDS arena: [hi patch | lo patch | weight fragments] during the K loop, re-used as the output staging tile
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * CV_PH * CV_PW * CV_PIX_STRIDE * 2 + CV_WFRAGS * 16];
+    unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
+    unsigned short* s_lo = s_hi + CV_PH * CV_PW * CV_PIX_STRIDE;
+    f16x8* s_w = reinterpret_cast<f16x8*>(s_raw + 2 * CV_PH * CV_PW * CV_PIX_STRIDE * 2);
+    float* s_out = reinterpret_cast<float*>(s_raw);       // [48 co][8 rows][CV_OUT_STRIDE] = 55296 B <= arena (63360 B)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_cob = C_out / CV_COB;
-    const int b = blockIdx.z / n_cob, cob = blockIdx.z % n_cob;
-    const int y0 = blockIdx.y * CV_TH, x0 = blockIdx.x * CV_TW;
-    const int n_cb = C_in / CV_CB;
+    const int n_cob = C_out / CV_COB, n_cb = C_in / CV_CB;
+    const int tiles_x = W / CV_TW, tiles_y = H / CV_TH;
     const size_t plane = (size_t)H * W;
-    const float* xb = x + (size_t)b * C_in * plane;
+
+    // this workgroup's slice of the work list (host guarantees gridDim.x % 8 == 0)
+    const int G = gridDim.x >> 3;                              // workgroups per XCD
+    const int strip = (n_work + 7) >> 3;                       // work items per XCD
+    const int strip_lo = (blockIdx.x & 7) * strip;
+    const int strip_hi = min(n_work, strip_lo + strip);
+    const int first = strip_lo + (blockIdx.x >> 3);
+    if (first >= strip_hi) return;                             // uniform per workgroup
+    const int n_mine = (strip_hi - first + G - 1) / G;
+    const int n_stage = n_mine * n_cb;
 
     f32x4 acc[CV_MT][4];
 #pragma unroll
@@ -57,32 +94,45 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
 
     const int g = lane >> 4, px = lane & 15;
     const int ci_off = 8 * (g & 1);
-    const f16x8* wbase = wpk + (size_t)cob * n_cb * CV_WFRAGS;
 
-    // per-thread staging coordinates (fixed across stages)
-    int a_off[CV_ACT_ITERS];                // LDS element offset, -1 = no work
-    int a_src[CV_ACT_ITERS];                // pixel offset inside the plane, -1 = outside the image (zero padding)
-    int a_c4[CV_ACT_ITERS];
+    // per-thread staging coordinates: one aligned float4 (4 pixels) of 4 channels per item; tile-independent parts
+    int a_pix[CV_ACT_ITERS];                // patch pixel index of the row start
+    int a_col[CV_ACT_ITERS];                // patch column of the float4's first element (-3 .. 33)
+    int a_c4[CV_ACT_ITERS];                 // channel quad, -1 = no item
+    int a_py[CV_ACT_ITERS];
 #pragma unroll
     for (int i = 0; i < CV_ACT_ITERS; ++i) {
         const int e = tid + 256 * i;
-        if (e < CV_PH * CV_PW * (CV_CB / 4)) {
-            const int c4 = e / (CV_PH * CV_PW);
-            const int p = e - c4 * (CV_PH * CV_PW);
-            const int py = p / CV_PW, pxx = p - py * CV_PW;
-            const int gy = y0 + py - 1, gx = x0 + pxx - 1;
-            a_off[i] = p * CV_PIX_STRIDE + c4 * 4;
-            a_c4[i] = c4;
-            a_src[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+        if (e < CV_ITEMS) {
+            const int c4 = e / (CV_PH * CV_QUADS);
+            const int r = e - c4 * (CV_PH * CV_QUADS);
+            const int py = r / CV_QUADS, qd = r - py * CV_QUADS;
+            a_c4[i] = c4; a_col[i] = 4 * qd - 3; a_pix[i] = py * CV_PW; a_py[i] = py;
         } else {
-            a_off[i] = -1; a_src[i] = -1; a_c4[i] = 0;
+            a_c4[i] = -1; a_col[i] = 0; a_pix[i] = 0; a_py[i] = 0;
         }
     }
-    float pre_x[CV_ACT_ITERS][4];
+    float4 pre_x[CV_ACT_ITERS][4];
     f16x8 pre_w[CV_W_ITERS];
 
-    auto prefetch = [&](int cb) {
-        const f16x8* wcb = wbase + (size_t)cb * CV_WFRAGS;
+    // loader-side tile state (runs one stage ahead of the compute side)
+    int l_item = 0, l_cb = 0;
+    int l_src[CV_ACT_ITERS];                // float offset of the float4 inside a plane, -1 = outside the image (zeros)
+    const float* l_xb = x;
+    const f16x8* l_wbase = wpk;
+    auto loader_tile = [&](int item) {
+        const cv_tile t = cv_decode(first + item * G, n_cob, tiles_x, tiles_y, bw);
+        l_xb = x + (size_t)t.b * C_in * plane;
+        l_wbase = wpk + (size_t)t.cob * n_cb * CV_WFRAGS;
+#pragma unroll
+        for (int i = 0; i < CV_ACT_ITERS; ++i) {
+            const int gy = t.y0 + a_py[i] - 1, gx = t.x0 - 1 + a_col[i];          // gx is 4-aligned (x0 % 32 == 0)
+            l_src[i] = (a_c4[i] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+        }
+    };
+    auto prefetch = [&]() {
+        if (mode >= 6) { if (s_raw[0] == 77) pre_w[0] = wpk[tid]; if (++l_cb == n_cb) { l_cb = 0; if (++l_item < n_mine) loader_tile(l_item); } return; }                 // issue the global loads of stage (l_item, l_cb), then advance the loader
+        const f16x8* wcb = l_wbase + (size_t)l_cb * CV_WFRAGS;
 #pragma unroll
         for (int i = 0; i < CV_W_ITERS; ++i) {
             const int e = tid + 256 * i;
@@ -92,15 +142,23 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ci = cb * CV_CB + a_c4[i] * 4 + q;
-                pre_x[i][q] = (a_src[i] >= 0) ? xb[(size_t)ci * plane + a_src[i]] : 0.f;
+                const int ci = l_cb * CV_CB + (a_c4[i] < 0 ? 0 : a_c4[i]) * 4 + q;
+                pre_x[i][q] = (l_src[i] >= 0) ? *reinterpret_cast<const float4*>(l_xb + (size_t)ci * plane + l_src[i])
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+        if (++l_cb == n_cb) {
+            l_cb = 0;
+            if (++l_item < n_mine) loader_tile(l_item);
         }
     };
 
-    prefetch(0);
-    for (int cb = 0; cb < n_cb; ++cb) {
-        __syncthreads();                 // previous stage fully consumed
+    loader_tile(0);
+    prefetch();
+    int c_item = 0, c_cb = 0;
+    for (int s = 0; s < n_stage; ++s) {
+        __syncthreads();
+        if (mode < 6) {
 #pragma unroll
         for (int i = 0; i < CV_W_ITERS; ++i) {
             const int e = tid + 256 * i;
@@ -108,21 +166,28 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         }
 #pragma unroll
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
-            if (a_off[i] < 0 || mode == 2) continue;
-            unsigned short h4[4], l4[4];
+            if (a_c4[i] < 0) continue;
+            const float* v4[4] = {&pre_x[i][0].x, &pre_x[i][1].x, &pre_x[i][2].x, &pre_x[i][3].x};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v = fminf(fmaxf(pre_x[i][q], -65504.f), 65504.f);
-                const _Float16 hv = (_Float16)v;               // v_cvt_f16_f32, round to nearest even
-                h4[q] = f16_bits(hv);
-                l4[q] = f16_bits((_Float16)(v - (float)hv));
+            for (int k = 0; k < 4; ++k) {                              // 4 pixels of the float4
+                const int col = a_col[i] + k;
+                if (col < 0 || col >= CV_PW) continue;                 // the 6 alignment columns outside the patch
+                unsigned short h4[4], l4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fminf(fmaxf(v4[q][k], -65504.f), 65504.f);
+                    const _Float16 hv = (_Float16)v;                   // v_cvt_f16_f32, round to nearest even
+                    h4[q] = f16_bits(hv);
+                    l4[q] = f16_bits((_Float16)(v - (float)hv));
+                }
+                const int off = (a_pix[i] + col) * CV_PIX_STRIDE + a_c4[i] * 4;
+                *reinterpret_cast<uint2*>(&s_hi[off]) = make_uint2((unsigned)h4[0] | ((unsigned)h4[1] << 16), (unsigned)h4[2] | ((unsigned)h4[3] << 16));
+                *reinterpret_cast<uint2*>(&s_lo[off]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
             }
-            *reinterpret_cast<uint2*>(&s_hi[a_off[i]]) = make_uint2((unsigned)h4[0] | ((unsigned)h4[1] << 16), (unsigned)h4[2] | ((unsigned)h4[3] << 16));
-            *reinterpret_cast<uint2*>(&s_lo[a_off[i]]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
+        }
         }
         __syncthreads();
-        if (cb + 1 < n_cb) prefetch(cb + 1);
-        if (mode == 1) continue;
+        if (s + 1 < n_stage) prefetch();   // the next stage's global loads fly under this stage's MFMAs (and stores)
 #pragma unroll
         for (int pair = 0; pair < 5; ++pair) {
             int tap = pair * 2 + (g >> 1);
@@ -131,15 +196,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
             f16x8 ah[CV_MT], al[CV_MT];
 #pragma unroll
             for (int m = 0; m < CV_MT; ++m) {
+                if (mode == 7) { ah[m] = pre_w[m]; al[m] = pre_w[m+3]; } else {
                 ah[m] = s_w[((pair * 2 + 0) * CV_MT + m) * 64 + lane];
-                al[m] = s_w[((pair * 2 + 1) * CV_MT + m) * 64 + lane];
+                al[m] = s_w[((pair * 2 + 1) * CV_MT + m) * 64 + lane]; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
                 const int off = ((ty + dy) * CV_PW + (tx + dx)) * CV_PIX_STRIDE + ci_off;
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(&s_hi[off]);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+                f16x8 bh, bl;
+                if (mode == 7) { bh = ah[0]; bl = al[0]; } else {
+                bh = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+                bl = *reinterpret_cast<const f16x8*>(&s_lo[off]); }
 #pragma unroll
                 for (int m = 0; m < CV_MT; ++m) {
                     acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][q], 0, 0, 0);
@@ -148,21 +216,37 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                 }
             }
         }
-    }
-    // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15]
-    float* ob = out + ((size_t)b * C_out + (size_t)cob * CV_COB) * plane;
+        if (++c_cb < n_cb) continue;
+        // ---- tile done: accumulators (D[row = (lane>>4)*4 + r][col = lane&15]) -> LDS [co][row][x] -> 128-byte row stores
+        c_cb = 0;
+        const cv_tile t = cv_decode(first + c_item * G, n_cob, tiles_x, tiles_y, bw);
+        ++c_item;
+        __syncthreads();                 // all waves done with the stage buffers
 #pragma unroll
-    for (int m = 0; m < CV_MT; ++m) {
+        for (int m = 0; m < CV_MT; ++m) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int yy = y0 + 2 * wave + (q >> 1), xx = x0 + (q & 1) * 16 + px;
+            for (int q = 0; q < 4; ++q) {
+                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = m * 16 + g * 4 + r;
-                float v = acc[m][q][r] * w_unscale + bias[cob * CV_COB + co];
-                if (RELU) v = fmaxf(v, 0.f);
-                if (mode != 3) ob[(size_t)co * plane + (size_t)yy * W + xx] = v; else if (v == 12345.678f) ob[0] = v;
+                for (int r = 0; r < 4; ++r) {
+                    const int co = m * 16 + g * 4 + r;
+                    float v = acc[m][q][r] * w_unscale + bias[t.cob * CV_COB + co];
+                    if (RELU) v = fmaxf(v, 0.f);
+                    s_out[(co * CV_TH + ty) * CV_OUT_STRIDE + tx] = v;
+                }
+                acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        }
+        __syncthreads();
+        float* ob = out + ((size_t)t.b * C_out + (size_t)t.cob * CV_COB) * plane + (size_t)t.y0 * W + t.x0;
+        // 48 co x 8 rows x 8 float4 = 3072 float4 over 256 threads: 8 consecutive threads write one 128-byte row segment
+        if ((mode != 3 && mode < 6) || acc[0][0][0] == 12345.f)
+#pragma unroll 4
+        for (int e = tid; e < CV_COB * CV_TH * (CV_TW / 4); e += 256) {
+            const int line = e >> 3, q4 = e & 7;
+            const int co = line >> 3, ty = line & 7;
+            const float4 v = *reinterpret_cast<const float4*>(&s_out[line * CV_OUT_STRIDE + 4 * q4]);
+            *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)ty * W + 4 * q4) = v;
         }
     }
 }
@@ -173,13 +257,19 @@ extern "C" int exp_conv(ac_ctx* ctx, const float* x, const void* w_packed, const
     AC_REQUIRE(B > 0 && C_in > 0 && C_in % CV_CB == 0 && C_out > 0 && C_out % CV_COB == 0, "C_in % 16 == 0 and C_out % 48 == 0");
     AC_REQUIRE(H > 0 && H % CV_TH == 0 && W > 0 && W % CV_TW == 0, "H % 8 == 0 and W % 32 == 0");
     AC_REQUIRE((long long)H * W < (1LL << 31), "plane too large");
-    const long long gz = (long long)B * (C_out / CV_COB);
-    AC_REQUIRE(gz <= 65535 && H / CV_TH <= 65535, "grid too large");
-    dim3 grid(W / CV_TW, H / CV_TH, (unsigned)gz), block(256);
+    const long long n_work = (long long)B * (C_out / CV_COB) * (H / CV_TH) * (W / CV_TW);
+    AC_REQUIRE(n_work < (1LL << 30), "work list too large");
+    const int tiles_x = W / CV_TW;
+    const int bw = tiles_x % 4 == 0 ? 4 : (tiles_x % 3 == 0 ? 3 : (tiles_x % 2 == 0 ? 2 : 1));   // column-band width (tiles)
+    // persistent grid: 2 workgroups per CU (LDS-bound occupancy), a multiple of 8 so every XCD gets the same count
+    long long nblk = 2LL * ctx->n_cu;
+    if (nblk > n_work) nblk = n_work;
+    nblk = ((nblk + 7) / 8) * 8;
+    dim3 grid((unsigned)nblk), block(256);
     if (relu)
-        hipLaunchKernelGGL(k_conv3x3_f16x3<true>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, mode);
+        hipLaunchKernelGGL(k_conv3x3_f16x3<true>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw, (int)n_work, mode);
     else
-        hipLaunchKernelGGL(k_conv3x3_f16x3<false>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, mode);
+        hipLaunchKernelGGL(k_conv3x3_f16x3<false>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw, (int)n_work, mode);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

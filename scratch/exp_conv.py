@@ -15,6 +15,6 @@ for (B,c,H,W) in [(16,48,256,3072),(16,96,128,1536)]:
     x=torch.randn(B,c,H,W,device='cuda'); w=torch.randn(c,c,3,3)/np.sqrt(9*c); b=torch.randn(c,device='cuda')
     pk,un=pack_conv3x3(w.numpy()); wp=torch.from_numpy(pk.view(np.int16)).cuda()
     out=torch.empty_like(x)
-    for mode,name in [(0,'full'),(1,'no mfma'),(2,'no cvt+lds write'),(3,'no output stores')]:
+    for mode,name in [(0,'full'),(3,'no output stores'),(6,'LDS reads + MFMA only'),(7,'MFMA only')]:
         t=bench(lambda: lib.exp_conv(hip._h, x.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr(), B,c,c,H,W, un, 1, None, mode))
         print(f"c{c}: {name:20s} {t:.2f} ms")

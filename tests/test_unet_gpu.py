@@ -42,11 +42,13 @@ def test_unet_blocks_and_output_vs_float64(hip_ctx):
     out_err = float((yg - y64).abs().max() / y64.abs().max())
     print(f"output error vs float64: {out_err:.2e}")
     assert out_err < 1e-5           # float32-class: the split-f16 convs keep 22 mantissa bits
-    hip_ctx.conv_impl = "miopen"                                            # float32 MIOpen convs: plain float32 accuracy
+    hip_ctx.conv_impl = "miopen"                                            # float32 MIOpen convs + rocBLAS TDF: plain float32 accuracy
+    hip_ctx.tdf_impl = "rocblas"
     try:
         y32 = netg(x.to(hip_ctx.device)).double().cpu()
     finally:
         hip_ctx.conv_impl = "f16x3"
+        hip_ctx.tdf_impl = "f16x3"
     assert float((y32 - y64).abs().max() / y64.abs().max()) < 1e-5
     # the un-fused oracle graph (conv -> BN -> ReLU as separate float32 ops) agrees with the folded net
     yo = unet_forward(x, w).double()
@@ -78,6 +80,30 @@ def test_conv3x3_f16x3_kernel(hip_ctx):
         assert float((got - edge).abs().max() / edge.abs().max()) < 2e-6
 
 
+def test_tdf_linear_f16x3_kernel(hip_ctx):
+    """ac_tdf_linear_f16x3 (GEMM + per-channel affine + ReLU (+ residual)) against float64 on the U-Net's TDF shapes."""
+    import torch.nn.functional as F
+    from audio_cut_amd.separation.conv_pack import pack_linear
+    g = torch.Generator().manual_seed(3)
+    dev = hip_ctx.device
+    for (b, c, t, k, n) in ((2, 48, 256, 3072, 384), (2, 48, 256, 384, 3072), (2, 96, 128, 1536, 192), (2, 96, 128, 192, 1536),
+                            (2, 144, 64, 768, 96), (2, 144, 64, 96, 768), (1, 48, 8, 96, 96), (3, 48, 8, 32, 288)):
+        x = (torch.randn(b, c, t, k, generator=g) * 3).to(dev)
+        wt = torch.randn(n, k, generator=g) / np.sqrt(k)           # asymmetric: catches a transposed operand
+        sc = (torch.rand(c, generator=g) + 0.5).to(dev); sh = (torch.randn(c, generator=g) * 0.3).to(dev)
+        packed, unscale = pack_linear(wt.numpy())
+        wp = torch.from_numpy(packed.view(np.int16)).to(dev)
+        for with_resid in (False, True):
+            r = torch.randn(b, c, t, n, generator=g).to(dev) if with_resid else None
+            y = hip_ctx.tdf_linear_f16x3(x, wp, n, sc, sh, unscale, resid=r).double().cpu()
+            ref = torch.relu(F.linear(x.double().cpu(), wt.double()) * sc.double().cpu().view(1, -1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1))
+            if with_resid:
+                ref = ref + r.double().cpu()
+            assert float((y - ref).abs().max() / ref.abs().max()) < 3e-6, (b, c, t, k, n, with_resid)
+    with pytest.raises(Exception):
+        hip_ctx.tdf_linear_f16x3(torch.zeros(1, 3, 5, 32, device=dev), wp, 96, sc, sh, 1.0)     # rows % 128 != 0: refused, not mis-tiled
+
+
 def test_fused_epilogues_match_the_unfused_torch_ops(hip_ctx):
     """TfcTdfNet with the HIP epilogues (bias+ReLU, affine+ReLU(+residual), bias+ReLU*skip) == plain PyTorch elementwise ops."""
     spec = TfcTdfSpec()
@@ -86,11 +112,13 @@ def test_fused_epilogues_match_the_unfused_torch_ops(hip_ctx):
     x = (torch.randn(2, 4, 32, 3072, generator=g) * 3.0).to(hip_ctx.device)
     plain = TfcTdfNet(w, spec).to(hip_ctx.device).eval()
     fused = TfcTdfNet(w, spec, hip=hip_ctx).to(hip_ctx.device).eval()
-    hip_ctx.conv_impl = "miopen"        # same float32 MIOpen convs on both sides: only the epilogues differ
+    hip_ctx.conv_impl = "miopen"        # same float32 MIOpen convs / rocBLAS GEMMs on both sides: only the epilogues differ
+    hip_ctx.tdf_impl = "rocblas"
     try:
         a = plain.forward_tf(x); b = fused.forward_tf(x)
     finally:
         hip_ctx.conv_impl = "f16x3"
+        hip_ctx.tdf_impl = "f16x3"
     assert float((a - b).abs().max() / a.abs().max()) < 2e-6
     # the kernels themselves, on odd row counts
     t = torch.randn(3, 5, 7, 12, device=hip_ctx.device); bias = torch.randn(5, device=hip_ctx.device)
