@@ -78,6 +78,9 @@ SIGNATURES = {
     "ac_depth_to_space2x_bias_relu_mul": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P]),
+    "ac_conv1x1_small": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I64, _I, _P]),
+    "ac_down2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P]),
+    "ac_up2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -127,6 +130,9 @@ class Context:
         self.conv_impl = os.environ.get("AUDIOCUT_CONV_IMPL", "f16x3")
         # TDF layers: "f16x3" = ac_tdf_linear_f16x3 (fused GEMM + affine + ReLU (+ residual)), "rocblas" = float32 rocBLAS + epilogues
         self.tdf_impl = os.environ.get("AUDIOCUT_TDF_IMPL", "f16x3")
+        # 2x2 resampling layers: "f16x3" = ac_down2x_f16x3 / ac_up2x_f16x3 (one fused MFMA kernel each),
+        # "gemm" = gather/scatter kernels around a rocBLAS float32 GEMM, "miopen" = strided / transposed convolutions
+        self.resample_impl = os.environ.get("AUDIOCUT_RESAMPLE_IMPL", "f16x3")
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -374,6 +380,40 @@ class Context:
             raise NativeError("tdf_linear_f16x3: residual must match the output")
         _check(self.lib.ac_tdf_linear_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(resid), _ptr(out),
                                             b * c * t, n_out, k, t, c, float(w_unscale), _stream()))
+        return out
+
+    def conv1x1_small(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
+        """1x1 conv with min(C_in, C_out) <= 8 (+ bias, optional ReLU) as a streaming float32 kernel.  NCHW float32."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("conv1x1_small expects a contiguous float32 NCHW tensor")
+        b, c, h, w = x.shape
+        w2 = weight.reshape(weight.shape[0], -1)
+        if w2.shape[1] != c or not w2.is_contiguous():
+            raise NativeError("conv1x1_small: weight must be [C_out, C_in(,1,1)] contiguous")
+        out = torch.empty((b, w2.shape[0], h, w), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_conv1x1_small(self._h, _ptr(x), _ptr(w2), _ptr(bias), _ptr(out), b, c, w2.shape[0], h * w, int(relu), _stream()))
+        return out
+
+    def down2x_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float) -> torch.Tensor:
+        """2x2 / stride-2 conv + bias + ReLU, one fused MFMA kernel (space-to-depth gather in the loader).  NCHW float32."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("down2x_f16x3 expects a contiguous float32 NCHW tensor")
+        b, c, h, w = x.shape
+        out = torch.empty((b, c_out, h // 2, w // 2), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_down2x_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c, c_out, h, w, float(w_unscale), _stream()))
+        return out
+
+    def up2x_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float,
+                   skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """2x2 / stride-2 transposed conv + bias + ReLU (* skip), one fused MFMA kernel (depth-to-space in the epilogue)."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("up2x_f16x3 expects a contiguous float32 NCHW tensor")
+        b, c, h, w = x.shape
+        out = torch.empty((b, c_out, 2 * h, 2 * w), dtype=torch.float32, device=self.device)
+        if skip is not None and (skip.shape != out.shape or not skip.is_contiguous() or skip.dtype != torch.float32):
+            raise NativeError("up2x_f16x3: skip must match the output")
+        _check(self.lib.ac_up2x_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(skip), _ptr(out), b, c, c_out, h, w,
+                                      float(w_unscale), _stream()))
         return out
 
     def mean_square(self, x: torch.Tensor) -> float:

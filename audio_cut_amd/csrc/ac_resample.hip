@@ -1,0 +1,285 @@
+// The U-Net's 2x2 / stride-2 resampling layers as ONE fused kernel each, on the 16-bit matrix cores with the 3-term
+// float16 split of ac_conv.hip / ac_gemm.hip (float32-class products, float32 accumulation):
+//   down: out[b][co][y][x]       = relu(bias[co] + sum_{ci,dy,dx} x[b][ci][2y+dy][2x+dx] * w[co][ci][dy][dx])
+//   up:   out[b][co][2y+dy][2x+dx] = relu(bias[co] + sum_ci x[b][ci][y][x] * w[ci][co][dy][dx]) * skip[b][co][2y+dy][2x+dx]
+// Both are GEMMs over pixels: A[m][k] with m = pixel (b, y, x) and k = (ci, dy, dx) (down) or ci (up), B = packed
+// weights [N][K] (N = co for down, (co, dy, dx) for up; conv_pack.pack_linear with bn = 96, zero padded).  The gather
+// (space-to-depth) lives in the A loader, the scatter (depth-to-space), bias, ReLU and skip product in the epilogue,
+// so each layer reads its input once and writes its output once.
+//
+// Workgroup: 256 threads = 2 x 2 waves, tile 128 pixels x 96 columns, wave tile 64 x 48; K in stages of 32; the next
+// stage's global loads are issued before the current stage's MFMAs (same structure as k_tdf_linear_f16x3).
+#include "ac_common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define RS_BM 128
+#define RS_BN 96
+#define RS_BK 32
+#define RS_ASTRIDE 40            // f16 per staged pixel row (32 used + 8 pad -> 80 bytes, conflict-free ds_read_b128)
+#define RS_MT 4
+#define RS_NT 3
+#define RS_BFRAGS (2 * (RS_BN / 16) * 64)          // 768 16-byte weight fragments per stage
+#define RS_B_ITERS (RS_BFRAGS / 256)               // 3
+
+__device__ inline unsigned rs_pack_hi(float a, float b, unsigned& lo_out) {
+    const float ca = fminf(fmaxf(a, -65504.f), 65504.f), cb = fminf(fmaxf(b, -65504.f), 65504.f);
+    const _Float16 ha = (_Float16)ca, hb = (_Float16)cb;
+    const _Float16 la = (_Float16)(ca - (float)ha), lb = (_Float16)(cb - (float)hb);
+    lo_out = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+__device__ inline void rs_put4(unsigned short* s_hi, unsigned short* s_lo, int off, float a, float b, float c, float d) {
+    unsigned l0, l1;
+    const unsigned h0 = rs_pack_hi(a, b, l0), h1 = rs_pack_hi(c, d, l1);
+    *reinterpret_cast<uint2*>(&s_hi[off]) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(&s_lo[off]) = make_uint2(l0, l1);
+}
+
+// MODE 0 = down (x [B][Ci][H][W] -> out [B][Co][H/2][W/2]);  MODE 1 = up (x [B][Ci][H][W] -> out [B][Co][2H][2W]).
+// P = pixels per image on the GEMM's M axis (down: (H/2)*(W/2); up: H*W), P % 128 == 0.
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
+                                                             const float* __restrict__ bias, const float* __restrict__ skip,
+                                                             float* __restrict__ out, int Ci, int Co, int H, int W,
+                                                             int n_stage, int n_nblk, int n_mblk, float w_unscale) {
+    constexpr int A_BYTES = 2 * RS_BM * RS_ASTRIDE * 2;                      // 20480
+    constexpr int OSTRIDE_UP = 48 + 4;                                       // up: strip [16 m][48 n]
+    constexpr int OSTRIDE_DN = 64 + 4;                                       // down: strip [16 n][64 m]
+    constexpr int O_BYTES = 4 * 16 * (MODE ? OSTRIDE_UP : OSTRIDE_DN) * 4;
+    constexpr int ARENA = (A_BYTES + RS_BFRAGS * 16) > O_BYTES ? (A_BYTES + RS_BFRAGS * 16) : O_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[ARENA];
+    unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
+    unsigned short* s_lo = s_hi + RS_BM * RS_ASTRIDE;
+    f16x8* s_b = reinterpret_cast<f16x8*>(s_raw + A_BYTES);
+    float* s_out = reinterpret_cast<float*>(s_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int wi = blockIdx.x;                                   // XCD-aware order: column blocks of one pixel tile are neighbours
+    if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int nb = wi % n_nblk, mb = wi / n_nblk;
+    if (mb >= n_mblk) return;
+    const int Ho = MODE ? H : (H >> 1), Wo = MODE ? W : (W >> 1);           // the M axis walks an Ho x Wo pixel grid
+    const int P = Ho * Wo;
+    const int tiles_per_img = P / RS_BM;
+    const int b = mb / tiles_per_img;
+    const int p0 = (mb - b * tiles_per_img) * RS_BM;                         // first pixel of the tile inside its image
+    const size_t plane_in = (size_t)H * W;
+    const float* xb = x + (size_t)b * Ci * plane_in;
+
+    f32x4 acc[RS_MT][RS_NT];
+#pragma unroll
+    for (int m = 0; m < RS_MT; ++m)
+#pragma unroll
+        for (int n = 0; n < RS_NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- A loader state --------------------------------------------------------------------------------------
+    // down: item (pixel pair p = e & 63, channel e >> 6 of the stage's 8), two float4 (dy = 0, 1) = 2 pixels x 4 taps
+    // up:   item (pixel quad q = tid & 31, channel quad tid >> 5 of the stage's 8), four float4 = 4 pixels x 4 channels
+    constexpr int A_LD = MODE ? 4 : 4;                       // float4 loads per thread per stage (both modes: 4)
+    float4 pre_a[A_LD];
+    f16x8 pre_b[RS_B_ITERS];
+    size_t dn_src[2];
+    int dn_ci[2], dn_off[2];
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i;
+            const int cl = e >> 6, p = e & 63;
+            const int pix = p0 + 2 * p;
+            const int yo = pix / Wo, xo = pix - yo * Wo;
+            dn_ci[i] = cl;
+            dn_src[i] = (size_t)(2 * yo) * W + 2 * xo;
+            dn_off[i] = (2 * p) * RS_ASTRIDE + cl * 4;
+        }
+    }
+    const int up_c4 = tid >> 5, up_q = tid & 31;
+    const f16x8* wbase = wpk + (size_t)nb * n_stage * RS_BFRAGS;
+
+    auto prefetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < RS_B_ITERS; ++i) pre_b[i] = wbase[(size_t)s * RS_BFRAGS + tid + 256 * i];
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = xb + (size_t)(s * 8 + dn_ci[i]) * plane_in + dn_src[i];
+                pre_a[2 * i + 0] = *reinterpret_cast<const float4*>(src);
+                pre_a[2 * i + 1] = *reinterpret_cast<const float4*>(src + W);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = s * RS_BK + up_c4 * 4 + j;
+                pre_a[j] = (ci < Ci) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane_in + p0 + 4 * up_q)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < RS_B_ITERS; ++i) s_b[tid + 256 * i] = pre_b[i];
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 r0 = pre_a[2 * i], r1 = pre_a[2 * i + 1];          // (px0 dx0, px0 dx1, px1 dx0, px1 dx1) for dy = 0 / 1
+                rs_put4(s_hi, s_lo, dn_off[i], r0.x, r0.y, r1.x, r1.y);
+                rs_put4(s_hi, s_lo, dn_off[i] + RS_ASTRIDE, r0.z, r0.w, r1.z, r1.w);
+            }
+        } else {
+            const int off = (4 * up_q) * RS_ASTRIDE + up_c4 * 4;
+            rs_put4(s_hi, s_lo, off + 0 * RS_ASTRIDE, pre_a[0].x, pre_a[1].x, pre_a[2].x, pre_a[3].x);
+            rs_put4(s_hi, s_lo, off + 1 * RS_ASTRIDE, pre_a[0].y, pre_a[1].y, pre_a[2].y, pre_a[3].y);
+            rs_put4(s_hi, s_lo, off + 2 * RS_ASTRIDE, pre_a[0].z, pre_a[1].z, pre_a[2].z, pre_a[3].z);
+            rs_put4(s_hi, s_lo, off + 3 * RS_ASTRIDE, pre_a[0].w, pre_a[1].w, pre_a[2].w, pre_a[3].w);
+        }
+    };
+
+    const int frag_row = lane & 15, frag_k = 8 * (lane >> 4);
+    prefetch(0);
+    for (int s = 0; s < n_stage; ++s) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (s + 1 < n_stage) prefetch(s + 1);
+        f16x8 ah[RS_MT], al[RS_MT];
+#pragma unroll
+        for (int m = 0; m < RS_MT; ++m) {
+            const int off = (wm * 64 + m * 16 + frag_row) * RS_ASTRIDE + frag_k;
+            ah[m] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+            al[m] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+        }
+#pragma unroll
+        for (int n = 0; n < RS_NT; ++n) {
+            const f16x8 bh = s_b[(0 * (RS_BN / 16) + wn * RS_NT + n) * 64 + lane];
+            const f16x8 bl = s_b[(1 * (RS_BN / 16) + wn * RS_NT + n) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < RS_MT; ++m) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogues: D[row m = (lane >> 4) * 4 + r][col n = lane & 15]; strips are wave-private (LDS is in-order per wave)
+    const int g = lane >> 4, px = lane & 15;
+    __syncthreads();                     // every wave is done reading the stage buffers
+    if (MODE == 0) {
+        // down: NCHW output, pixels contiguous per channel.  Per n-tile: strip [16 n][64 m] -> 256-byte runs per channel.
+        float* so = s_out + wave * 16 * OSTRIDE_DN;
+        const size_t plane_out = (size_t)P;
+#pragma unroll
+        for (int n = 0; n < RS_NT; ++n) {
+#pragma unroll
+            for (int m = 0; m < RS_MT; ++m)
+                *reinterpret_cast<float4*>(&so[px * OSTRIDE_DN + m * 16 + 4 * g]) =
+                    make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = lane + 64 * i;
+                const int nn = e >> 4, q4 = e & 15;
+                const int co = nb * RS_BN + wn * 48 + n * 16 + nn;
+                if (co < Co) {
+                    const float bv = bias[co];
+                    float4 v = *reinterpret_cast<const float4*>(&so[nn * OSTRIDE_DN + 4 * q4]);
+                    v.x = fmaxf(v.x * w_unscale + bv, 0.f); v.y = fmaxf(v.y * w_unscale + bv, 0.f);
+                    v.z = fmaxf(v.z * w_unscale + bv, 0.f); v.w = fmaxf(v.w * w_unscale + bv, 0.f);
+                    *reinterpret_cast<float4*>(out + ((size_t)b * Co + co) * plane_out + p0 + wm * 64 + 4 * q4) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // up: column n = co * 4 + dy * 2 + dx.  Per m-tile: strip [16 m][48 n]; one float4 = 2 input pixels x (dx 0, 1) of one
+        // (co, dy): 8 consecutive lanes write a 128-byte run of an output row.  The skip rows are fetched one strip ahead.
+        float* so = s_out + wave * 16 * OSTRIDE_UP;
+        const int W2 = 2 * W;
+        const size_t plane_out = (size_t)4 * P;
+        float4 sk[2][3];
+        auto out_offset = [&](int m, int i, int& nn) -> size_t {
+            const int e = lane + 64 * i;                   // 192 float4 per strip: (co_dy = e >> 3) in 0..23, m pair = e & 7
+            const int cd = e >> 3, mp = e & 7;
+            nn = cd * 2;                                   // strip column of dx = 0
+            const int n_glob = nb * RS_BN + wn * 48 + nn;
+            const int co = n_glob >> 2, dy = (n_glob >> 1) & 1;
+            const int pix = p0 + wm * 64 + m * 16 + 2 * mp;
+            const int yy = pix / W, xx = pix - yy * W;
+            return ((size_t)b * Co + co) * plane_out + (size_t)(2 * yy + dy) * W2 + 2 * xx;
+        };
+        if (skip) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { int nn; sk[0][i] = *reinterpret_cast<const float4*>(skip + out_offset(0, i, nn)); }
+        }
+#pragma unroll
+        for (int m = 0; m < RS_MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < RS_NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) so[(g * 4 + r) * OSTRIDE_UP + n * 16 + px] = acc[m][n][r];
+            if (skip && m + 1 < RS_MT) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { int nn; sk[(m + 1) & 1][i] = *reinterpret_cast<const float4*>(skip + out_offset(m + 1, i, nn)); }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int nn;
+                const size_t o = out_offset(m, i, nn);
+                const int mp = (lane + 64 * i) & 7;
+                const int co = (nb * RS_BN + wn * 48 + nn) >> 2;
+                const float bv = bias[co];
+                const float2 a0 = *reinterpret_cast<const float2*>(&so[(2 * mp) * OSTRIDE_UP + nn]);       // pixel 2mp:   dx 0, 1
+                const float2 a1 = *reinterpret_cast<const float2*>(&so[(2 * mp + 1) * OSTRIDE_UP + nn]);   // pixel 2mp+1: dx 0, 1
+                float4 v = make_float4(fmaxf(a0.x * w_unscale + bv, 0.f), fmaxf(a0.y * w_unscale + bv, 0.f),
+                                       fmaxf(a1.x * w_unscale + bv, 0.f), fmaxf(a1.y * w_unscale + bv, 0.f));
+                if (skip) { const float4 q = sk[m & 1][i]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+                *reinterpret_cast<float4*>(out + o) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+static int rs_launch(int mode, ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out,
+                     int B, int Ci, int Co, int H, int W, float w_unscale, void* stream) {
+    AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
+    AC_REQUIRE(B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0, "positive sizes");
+    long long P;
+    int K, N;
+    if (mode == 0) {
+        AC_REQUIRE(H % 2 == 0 && W % 4 == 0 && Ci % 8 == 0, "down: H even, W % 4 == 0, C_in % 8 == 0");
+        P = (long long)(H / 2) * (W / 2); K = 4 * Ci; N = Co;
+    } else {
+        AC_REQUIRE(W % 4 == 0 && (4 * Co) % RS_BN == 0, "up: W % 4 == 0, 4 * C_out % 96 == 0");
+        P = (long long)H * W; K = Ci; N = 4 * Co;
+    }
+    AC_REQUIRE(P % RS_BM == 0, "pixels per image % 128 == 0");
+    AC_REQUIRE((long long)H * W * 4 < (1LL << 31), "plane too large");
+    const int n_stage = (K + RS_BK - 1) / RS_BK, n_nblk = (N + RS_BN - 1) / RS_BN;
+    const long long n_mblk = (long long)B * (P / RS_BM);
+    const long long nblk = n_mblk * n_nblk;
+    AC_REQUIRE(nblk < (1LL << 31) - 8, "grid too large");
+    dim3 grid((unsigned)nblk), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_resample2x_f16x3<0>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, skip, out,
+                           Ci, Co, H, W, n_stage, n_nblk, (int)n_mblk, w_unscale);
+    else
+        hipLaunchKernelGGL(k_resample2x_f16x3<1>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, skip, out,
+                           Ci, Co, H, W, n_stage, n_nblk, (int)n_mblk, w_unscale);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_down2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                                int C_out, int H, int W, float w_unscale, void* stream) {
+    return rs_launch(0, ctx, x, w_packed, bias, nullptr, out, B, C_in, C_out, H, W, w_unscale, stream);
+}
+
+extern "C" int ac_up2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out,
+                              int B, int C_in, int C_out, int H, int W, float w_unscale, void* stream) {
+    return rs_launch(1, ctx, x, w_packed, bias, skip, out, B, C_in, C_out, H, W, w_unscale, stream);
+}

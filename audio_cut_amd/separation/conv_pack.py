@@ -61,16 +61,27 @@ def linear_tileable(n_out: int, k_in: int, rows: int) -> bool:
     return rows % 128 == 0 and k_in % 32 == 0 and n_out % 96 == 0
 
 
-def pack_linear(weight: np.ndarray) -> Tuple[np.ndarray, float]:
-    """Linear weight [N, K] (y = x @ W^T) -> B-operand fragments of `v_mfma_f32_16x16x32_f16` for ac_tdf_linear_f16x3:
-    lane l of a fragment holds B[k = 8 (l >> 4) + j][n = l & 15] = W[n0 + (l & 15)][k0 + 8 (l >> 4) + j], j = 0..7.
-    Result: (uint16 [N/BN][K/32][2 (hi, lo)][BN/16][64][8], w_unscale) with BN = 192 when N % 192 == 0, else 96."""
+def pack_linear(weight: np.ndarray, bn: int = 0) -> Tuple[np.ndarray, float]:
+    """Linear weight [N, K] (y = x @ W^T) -> B-operand fragments of `v_mfma_f32_16x16x32_f16` for ac_tdf_linear_f16x3 /
+    ac_down2x_f16x3 / ac_up2x_f16x3: lane l of a fragment holds B[k = 8 (l >> 4) + j][n = l & 15]
+    = W[n0 + (l & 15)][k0 + 8 (l >> 4) + j], j = 0..7.
+    `bn` = columns per workgroup: 0 picks 192 when N % 192 == 0 else 96 and needs exact tiling (the TDF kernel);
+    an explicit `bn` zero-pads N to a multiple of it and K to a multiple of 32 (the resampling kernels).
+    Result: (uint16 [N'/bn][K'/32][2 (hi, lo)][bn/16][64][8], w_unscale)."""
+    weight = np.asarray(weight, dtype=np.float32)
     n, k = weight.shape
-    if n % 96 or k % 32:
-        raise ValueError("pack_linear needs N % 96 == 0 and K % 32 == 0")
-    bn = 192 if n % 192 == 0 else 96
+    if bn == 0:
+        if n % 96 or k % 32:
+            raise ValueError("pack_linear needs N % 96 == 0 and K % 32 == 0")
+        bn = 192 if n % 192 == 0 else 96
+    else:
+        n2, k2 = -(-n // bn) * bn, -(-k // 32) * 32
+        if (n2, k2) != (n, k):
+            padded = np.zeros((n2, k2), dtype=np.float32)
+            padded[:n, :k] = weight
+            weight, n, k = padded, n2, k2
     scale = weight_scale(weight)
-    hi, lo = split_hi_lo(np.asarray(weight, dtype=np.float32) * np.float32(scale))
+    hi, lo = split_hi_lo(weight * np.float32(scale))
     parts = np.stack([hi.view(np.uint16), lo.view(np.uint16)])            # [2, N, K]
     # [2, N/BN, BN/16, 16 (n in tile), K/32, 4 (lane group), 8 (j)]
     p = parts.reshape(2, n // bn, bn // 16, 16, k // 32, 4, 8)

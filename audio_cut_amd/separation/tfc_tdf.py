@@ -345,15 +345,30 @@ class TfcTdfNet(nn.Module):
             usw = torch.from_numpy(wf)                                         # [ci, co, 2, 2]
             self.register_buffer(f"us_m{i}", usw.permute(2, 3, 1, 0).reshape(-1, usw.shape[0]).contiguous())
         if hip is not None:
+            from .conv_pack import pack_linear
             for blk in [*self.enc, *self.dec, self.bottleneck]:
                 blk.pack_for_hip()
+            self._rs_unscale = {}
+            for i in range(spec.n_levels):
+                dsw = getattr(self, f"ds_w{i}").numpy()                        # [co, ci, 2, 2] -> W[co][(ci, dy, dx)]
+                packed, un = pack_linear(dsw.reshape(dsw.shape[0], -1), bn=96)
+                self.register_buffer(f"ds_p{i}", torch.from_numpy(packed.view(np.int16)))
+                self._rs_unscale[f"ds{i}"] = un
+                usw = getattr(self, f"us_w{i}").numpy()                        # [ci, co, 2, 2] -> W[(co, dy, dx)][ci]
+                packed, un = pack_linear(usw.transpose(1, 2, 3, 0).reshape(-1, usw.shape[0]), bn=96)
+                self.register_buffer(f"us_p{i}", torch.from_numpy(packed.view(np.int16)))
+                self._rs_unscale[f"us{i}"] = un
         self.register_buffer("final_w", torch.from_numpy(np.ascontiguousarray(w["final_conv.weight"])))
         self.register_buffer("final_b", torch.from_numpy(np.ascontiguousarray(w["final_conv.bias"])))
 
     def _down(self, x: torch.Tensor, i: int, hip) -> torch.Tensor:
         """2x2 / stride-2 conv + bias + ReLU = space-to-depth gather (HIP) + one [C', 4C] GEMM (rocBLAS) + fused epilogue."""
         b, c, h, w = x.shape
-        if getattr(hip, "resample_impl", "gemm") != "gemm" or h % 2 or w % 4:
+        impl = getattr(hip, "resample_impl", "f16x3")
+        if impl == "f16x3" and h % 2 == 0 and w % 4 == 0 and ((h // 2) * (w // 2)) % 128 == 0 and c % 8 == 0:
+            return hip.down2x_f16x3(x, getattr(self, f"ds_p{i}"), getattr(self, f"ds_b{i}"), getattr(self, f"ds_w{i}").shape[0],
+                                    self._rs_unscale[f"ds{i}"])
+        if impl == "miopen" or h % 2 or w % 4:
             return hip.bias_relu_(F.conv2d(x, getattr(self, f"ds_w{i}"), None, stride=2), getattr(self, f"ds_b{i}"))
         x2 = hip.space_to_depth2x(x).view(b, 4 * c, (h // 2) * (w // 2))
         y = torch.matmul(getattr(self, f"ds_m{i}"), x2).view(b, -1, h // 2, w // 2)
@@ -362,7 +377,11 @@ class TfcTdfNet(nn.Module):
     def _up(self, x: torch.Tensor, i: int, hip, skip: torch.Tensor) -> torch.Tensor:
         """2x2 / stride-2 transposed conv + bias + ReLU + multiplicative skip = one [4C', C] GEMM + one scatter pass."""
         b, c, h, w = x.shape
-        if getattr(hip, "resample_impl", "gemm") != "gemm" or w % 2:
+        impl = getattr(hip, "resample_impl", "f16x3")
+        c_out = getattr(self, f"us_w{i}").shape[1]
+        if impl == "f16x3" and w % 4 == 0 and (h * w) % 128 == 0 and (4 * c_out) % 96 == 0:
+            return hip.up2x_f16x3(x, getattr(self, f"us_p{i}"), getattr(self, f"us_b{i}"), c_out, self._rs_unscale[f"us{i}"], skip=skip)
+        if impl == "miopen" or w % 2:
             y = F.conv_transpose2d(x, getattr(self, f"us_w{i}"), None, stride=2)
             return hip.bias_relu_mul_(y, getattr(self, f"us_b{i}"), skip)
         y4 = torch.matmul(getattr(self, f"us_m{i}"), x.view(b, c, h * w)).view(b, -1, h, w)
@@ -382,7 +401,9 @@ class TfcTdfNet(nn.Module):
         hip = self.hip if (self.hip is not None and spec_tf.is_cuda) else None
         skips: List[torch.Tensor] = []
         if hip is not None:
-            x = hip.bias_relu_(F.conv2d(spec_tf, self.first_w, None), self.first_b)
+            ends_hip = (spec_tf.shape[2] * spec_tf.shape[3]) % 4 == 0 and spec_tf.is_contiguous()
+            x = hip.conv1x1_small(spec_tf, self.first_w, self.first_b, relu=True) if ends_hip \
+                else hip.bias_relu_(F.conv2d(spec_tf, self.first_w, None), self.first_b)
             for i in range(n):
                 x = self.enc[i](x, hip, self.conv_probe)
                 skips.append(x)
@@ -391,7 +412,7 @@ class TfcTdfNet(nn.Module):
             for i in range(n):
                 x = self._up(x, i, hip, skips.pop())
                 x = self.dec[i](x, hip, self.conv_probe)
-            return F.conv2d(x, self.final_w, self.final_b)
+            return hip.conv1x1_small(x, self.final_w, self.final_b, relu=False) if ends_hip else F.conv2d(x, self.final_w, self.final_b)
         x = F.relu_(F.conv2d(spec_tf, self.first_w, self.first_b))
         for i in range(n):
             x = self.enc[i](x)

@@ -194,6 +194,12 @@ int ac_depth_to_space2x_bias_relu_mul(ac_ctx* ctx, const float* y4, const float*
 int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                      int C_out, int H, int W, float w_unscale, int relu, void* stream);
 
+/* The graph's first (4 -> g) and last (g -> 4) 1x1 convolutions (Conv nodes at the two ends of the graph run at
+ * separation/backends.py:358; oracle/separator.py:78,94): float32 FMAs at streaming rate.
+ * out[b][co][p] = act(bias[co] + sum_ci w[co][ci] x[b][ci][p]); x [B][C_in][P], P % 4 == 0, min(C_in, C_out) <= 8. */
+int ac_conv1x1_small(ac_ctx* ctx, const float* x, const float* w, const float* bias, float* out, int B, int C_in, int C_out,
+                     long long P, int relu, void* stream);
+
 /* TDF layer of a TFC-TDF block (bias-free Linear over the frequency axis + eval BatchNorm2d over channels + ReLU;
  * the MatMul / BatchNormalization / Relu (/ Add) nodes of the graph run at separation/backends.py:358, restated in
  * oracle/separator.py:_tfc_tdf), same 3-term float16 split as ac_conv3x3_f16x3:
@@ -203,6 +209,19 @@ int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const fl
  * N % 192 == 0 else 96).  M % 128 == 0, K % 32 == 0, N % 96 == 0. */
 int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
                         const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale, void* stream);
+
+/* The U-Net's 2x2 / stride-2 resampling layers (Conv stride 2 / ConvTranspose stride 2 + BatchNormalization + Relu
+ * (+ Mul with the encoder skip) nodes of the graph run at separation/backends.py:358; oracle/separator.py:85-91),
+ * one fused kernel each, 3-term float16 split on the matrix cores:
+ *   down: out[b][co][y][x]         = relu(bias[co] + w_unscale * sum x[b][ci][2y+dy][2x+dx] w[co][ci][dy][dx])
+ *   up:   out[b][co][2y+dy][2x+dx] = relu(bias[co] + w_unscale * sum x[b][ci][y][x] w[ci][co][dy][dx]) * skip[...]  (skip may be NULL)
+ * x [B][C_in][H][W] float32 NCHW; w_packed = conv_pack.pack_linear(W, bn=96) of W[co][(ci,dy,dx)] (down) or
+ * W[(co,dy,dx)][ci] (up), zero padded to N % 96 == 0, K % 32 == 0.  Pixels per image on the GEMM's M axis
+ * ((H/2)*(W/2) down, H*W up) % 128 == 0; W % 4 == 0; down: H even, C_in % 8 == 0; up: 4*C_out % 96 == 0. */
+int ac_down2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
+                    int H, int W, float w_unscale, void* stream);
+int ac_up2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out, int B,
+                  int C_in, int C_out, int H, int W, float w_unscale, void* stream);
 
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 

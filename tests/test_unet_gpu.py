@@ -44,11 +44,13 @@ def test_unet_blocks_and_output_vs_float64(hip_ctx):
     assert out_err < 1e-5           # float32-class: the split-f16 convs keep 22 mantissa bits
     hip_ctx.conv_impl = "miopen"                                            # float32 MIOpen convs + rocBLAS TDF: plain float32 accuracy
     hip_ctx.tdf_impl = "rocblas"
+    hip_ctx.resample_impl = "gemm"
     try:
         y32 = netg(x.to(hip_ctx.device)).double().cpu()
     finally:
         hip_ctx.conv_impl = "f16x3"
         hip_ctx.tdf_impl = "f16x3"
+        hip_ctx.resample_impl = "f16x3"
     assert float((y32 - y64).abs().max() / y64.abs().max()) < 1e-5
     # the un-fused oracle graph (conv -> BN -> ReLU as separate float32 ops) agrees with the folded net
     yo = unet_forward(x, w).double()
@@ -114,11 +116,13 @@ def test_fused_epilogues_match_the_unfused_torch_ops(hip_ctx):
     fused = TfcTdfNet(w, spec, hip=hip_ctx).to(hip_ctx.device).eval()
     hip_ctx.conv_impl = "miopen"        # same float32 MIOpen convs / rocBLAS GEMMs on both sides: only the epilogues differ
     hip_ctx.tdf_impl = "rocblas"
+    hip_ctx.resample_impl = "miopen"
     try:
         a = plain.forward_tf(x); b = fused.forward_tf(x)
     finally:
         hip_ctx.conv_impl = "f16x3"
         hip_ctx.tdf_impl = "f16x3"
+        hip_ctx.resample_impl = "f16x3"
     assert float((a - b).abs().max() / a.abs().max()) < 2e-6
     # the kernels themselves, on odd row counts
     t = torch.randn(3, 5, 7, 12, device=hip_ctx.device); bias = torch.randn(5, device=hip_ctx.device)
@@ -151,3 +155,51 @@ def test_gemm_form_resampling_matches_strided_convs(hip_ctx):
         y4 = torch.matmul(wu.permute(2, 3, 1, 0).reshape(-1, c), x.view(3, c, h * w_)).view(3, 4 * co, h, w_)
         got = hip_ctx.depth_to_space2x_bias_relu_mul(y4, bu, skip)
         assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_fused_resampling_kernels_vs_float64(hip_ctx):
+    """ac_down2x_f16x3 / ac_up2x_f16x3 (gather/scatter fused around the split-f16 MFMA GEMM) against float64 strided /
+    transposed convolutions, on U-Net level shapes incl. the channel counts that need N / K zero padding (144, 240)."""
+    import torch.nn.functional as F
+    from audio_cut_amd.separation.conv_pack import pack_linear
+    g = torch.Generator().manual_seed(5)
+    dev = hip_ctx.device
+    for c, h, w_ in ((48, 32, 3072), (96, 16, 1536), (144, 64, 768), (192, 32, 384), (240, 16, 192)):
+        x = (torch.randn(2, c, h, w_, generator=g) * 2)
+        co = c + 48
+        wd = torch.randn(co, c, 2, 2, generator=g) / np.sqrt(4 * c)
+        bd = torch.randn(co, generator=g) * 0.2
+        packed, un = pack_linear(wd.numpy().reshape(co, -1), bn=96)
+        got = hip_ctx.down2x_f16x3(x.to(dev), torch.from_numpy(packed.view(np.int16)).to(dev), bd.to(dev), co, un).double().cpu()
+        ref = F.relu(F.conv2d(x.double(), wd.double(), bd.double(), stride=2))
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6, ("down", c)
+    for c, h, w_ in ((288, 8, 96), (240, 16, 192), (192, 32, 384), (144, 64, 768), (96, 16, 1536)):
+        x = (torch.randn(2, c, h, w_, generator=g) * 2)
+        co = c - 48
+        wu = torch.randn(c, co, 2, 2, generator=g) / np.sqrt(c)
+        bu = torch.randn(co, generator=g) * 0.2
+        skip = torch.randn(2, co, 2 * h, 2 * w_, generator=g)
+        packed, un = pack_linear(wu.numpy().transpose(1, 2, 3, 0).reshape(-1, c), bn=96)
+        wp = torch.from_numpy(packed.view(np.int16)).to(dev)
+        ref = F.relu(F.conv_transpose2d(x.double(), wu.double(), bu.double(), stride=2))
+        got = hip_ctx.up2x_f16x3(x.to(dev), wp, bu.to(dev), co, un, skip=None).double().cpu()
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6, ("up", c)
+        got = hip_ctx.up2x_f16x3(x.to(dev), wp, bu.to(dev), co, un, skip=skip.to(dev)).double().cpu()
+        ref = ref * skip.double()
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6, ("up*skip", c)
+
+
+def test_conv1x1_small_kernel(hip_ctx):
+    """ac_conv1x1_small (the graph's first 4 -> g and last g -> 4 convolutions) against float64."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(6)
+    dev = hip_ctx.device
+    for ci, co, relu in ((4, 48, True), (48, 4, False), (3, 5, True), (7, 2, False)):
+        x = torch.randn(3, ci, 8, 100, generator=g) * 2
+        wt = torch.randn(co, ci, 1, 1, generator=g) / np.sqrt(ci)
+        b = torch.randn(co, generator=g)
+        got = hip_ctx.conv1x1_small(x.to(dev), wt.to(dev), b.to(dev), relu=relu).double().cpu()
+        ref = F.conv2d(x.double(), wt.double(), b.double())
+        ref = F.relu(ref) if relu else ref
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6, (ci, co)
