@@ -179,34 +179,59 @@ class EnhancedVocalSeparator:
         torch.cuda.synchronize(hip.device)
         h2d_ms = (time.perf_counter() - t0) * 1000.0
 
-        sep = backend.separate_track(mix_dev, sr, plans, timings)
+        mix_ready = torch.cuda.Event()
+        mix_ready.record()
+        # 1. queue the whole separation (no host synchronisation inside)
+        sep = backend.separate_track(mix_dev, sr, plans, timings, defer_sync=True)
+        sep_done = torch.cuda.Event()
+        sep_done.record()
 
-        # chunked VAD on the per-chunk vocals (enhanced_vocal_separator.py:331-333,412-417)
+        # 2. while the U-Net runs: everything that only needs the MIX (`ChunkFeatureBuilder`, BPM / beat analysis) on a
+        #    second, high-priority stream - its small kernels and downloads slot in between the U-Net's launches
+        live_plans = [p for p in plans if min(total, int(round(p.end_s * sr))) > max(0, int(round(p.start_s * sr)))]
+        side = self._side_stream(hip)
+        with torch.cuda.stream(side):
+            side.wait_event(mix_ready)
+            mix_dev.record_stream(side)
+            feature_builder = ChunkFeatureBuilder(sr=sr, use_gpu=True, device=str(hip.device), ctx=hip)
+            feature_builder.attach_track(hip, mix_dev)
+            for plan, (cs, ce, es, ee) in zip(live_plans, sep.chunk_ranges):
+                if ee > es:
+                    feature_builder.add_chunk_range(plan, cs, ce)
+            cache = feature_builder.finalize(audio)
+            # the stem downloads (pinned host memory) follow on the same side stream as soon as the separation is done,
+            # beside the VAD / marker / detector kernels of the main stream
+            t1 = time.perf_counter()
+            side.wait_event(sep_done)
+            sep.vocal.record_stream(side); sep.instrumental.record_stream(side)
+            vocal_h = torch.empty(sep.vocal.shape, dtype=torch.float32, pin_memory=True)
+            inst_h = torch.empty(sep.instrumental.shape, dtype=torch.float32, pin_memory=True)
+            vocal_h.copy_(sep.vocal, non_blocking=True)
+            inst_h.copy_(sep.instrumental, non_blocking=True)
+            stems_on_host = torch.cuda.Event()
+            stems_on_host.record()
+
+        # 3. chunked VAD on the per-chunk vocals (enhanced_vocal_separator.py:331-333,412-417)
         vad_fn = self._vad_inference_fn or EnergyGateVad(sr, hip)
         chunk_vad = SileroChunkVAD(sample_rate=sr, merge_gap_ms=float(get_config("advanced_vad.silero_merge_gap_ms", 120.0)),
                                    focus_pad_s=float(get_config("advanced_vad.focus_window_pad_s", 0.2)), inference_fn=vad_fn)
-        feature_builder = ChunkFeatureBuilder(sr=sr, use_gpu=True, device=str(hip.device), ctx=hip)
-        feature_builder.attach_track(hip, mix_dev)
-        live_plans = [p for p in plans if min(total, int(round(p.end_s * sr))) > max(0, int(round(p.start_s * sr)))]
         for plan, off, (cs, ce, es, ee) in zip(live_plans, sep.chunk_offsets, sep.chunk_ranges):
             chunk_vocal = sep.chunk_vocal[off: off + (ce - cs)]
             if isinstance(vad_fn, EnergyGateVad):
                 chunk_vad.process_chunk(plan, chunk_vocal, sr)
             else:       # injected VadFn contract: host float32 chunk
                 chunk_vad.process_chunk(plan, chunk_vocal.cpu().numpy(), sr)
-            if ee > es:
-                feature_builder.add_chunk_range(plan, cs, ce)
         vad_segments = chunk_vad.finalize()
-        cache = feature_builder.finalize(audio)
+        sep.finish()
 
-        t1 = time.perf_counter()
-        vocal = sep.vocal.cpu().numpy()
-        inst_np = sep.instrumental.cpu().numpy()
-        dtoh_ms = (time.perf_counter() - t1) * 1000.0
-        inst: Optional[np.ndarray] = inst_np if np.any(inst_np) else None      # `:458`
-
-        confidence = self._estimate_confidence_device(hip, sep.vocal, sep.instrumental if inst is not None else None, mix_dev)
+        inst_energy = hip.mean_square(sep.instrumental) if sep.instrumental.numel() else 0.0
+        has_inst = inst_energy > 0.0                                            # `:458` (`np.any(instrumental)`), reduced on the GPU
+        confidence = self._estimate_confidence_device(hip, sep.vocal, sep.instrumental if has_inst else None, mix_dev, inst_energy)
         markers = compute_vocal_presence_markers(hip, sep.vocal, sr)
+        stems_on_host.synchronize()
+        dtoh_ms = (time.perf_counter() - t1) * 1000.0
+        vocal = vocal_h.numpy()
+        inst = inst_h.numpy() if has_inst else None
 
         perf = backend.get_performance_metrics(reset=True)
         gm = gpu_context.gpu_meta
@@ -222,16 +247,24 @@ class EnhancedVocalSeparator:
         gm["gpu_pipeline_stage_ms"] = dict(timings)
         gpu_context.capture_device_metrics()
         state = {"hip": hip, "mix": mix_dev, "vocal": sep.vocal, "instrumental": sep.instrumental, "timings": timings}
-        return vocal.astype(np.float32), None if inst is None else inst.astype(np.float32), cache, vad_segments, markers, confidence, state
+        return vocal, inst, cache, vad_segments, markers, confidence, state
+
+    def _side_stream(self, hip) -> "torch.cuda.Stream":
+        """A second HIP stream (high priority) for the mix-only feature path that overlaps the U-Net."""
+        st = getattr(self, "_side", None)
+        if st is None or st.device != hip.device:
+            st = torch.cuda.Stream(device=hip.device, priority=-1)
+            self._side = st
+        return st
 
     @staticmethod
-    def _estimate_confidence_device(hip, vocal_dev, inst_dev, mix_dev) -> float:
+    def _estimate_confidence_device(hip, vocal_dev, inst_dev, mix_dev, inst_energy: Optional[float] = None) -> float:
         """`:490-501` with the three mean squares reduced on the GPU (float64 partials)."""
         ve = hip.mean_square(vocal_dev) if vocal_dev.numel() else 0.0
         me = hip.mean_square(mix_dev) if mix_dev.numel() else 1e-8
         ratio = float(np.clip(ve / (me + 1e-8), 0.0, 1.0))
         if inst_dev is not None and inst_dev.numel():
-            bal = ve / (hip.mean_square(inst_dev) + 1e-8)
+            bal = ve / ((hip.mean_square(inst_dev) if inst_energy is None else inst_energy) + 1e-8)
             return float(np.clip(0.5 * ratio + 0.5 * np.clip(bal / (1.0 + bal), 0.0, 1.0), 0.0, 1.0))
         return float(np.clip(ratio, 0.0, 1.0))
 

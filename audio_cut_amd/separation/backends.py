@@ -75,6 +75,7 @@ class TrackSeparation:
     chunk_offsets: List[int]       # start of chunk c inside chunk_vocal
     chunk_ranges: List[Tuple[int, int, int, int]]   # (chunk_start, chunk_end, eff_start, eff_end)
     n_items: int
+    finish: Optional[object] = None   # callable: waits for the queued work and fills the stage timings (separate_track(defer_sync=True))
 
 
 def items_per_chunk(chunk_len: int, align_hop: int) -> int:
@@ -170,8 +171,10 @@ class MDX23HipBackend(IVocalSeparatorBackend):
 
     # -- batched fast path ------------------------------------------------------------------------
     def separate_track(self, track_dev: torch.Tensor, sr: int, plans: Sequence[ChunkPlan],
-                       timings: Optional[Dict[str, float]] = None) -> TrackSeparation:
-        """All chunks of a resident track: STFT -> U-Net -> iSTFT -> stem assembly + OLA, no host bounce."""
+                       timings: Optional[Dict[str, float]] = None, defer_sync: bool = False) -> TrackSeparation:
+        """All chunks of a resident track: STFT -> U-Net -> iSTFT -> stem assembly + OLA, no host bounce.
+        Everything is queued on the current stream without a host synchronisation; `defer_sync=True` returns at once
+        (the caller overlaps host work and calls `result.finish()` later), otherwise the timings are read before returning."""
         hip = self.hip
         net = self.net
         n = int(track_dev.numel())
@@ -191,8 +194,15 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             for k in range(items_per_chunk(ce - cs, self._align_hop)):
                 cs_items.append(cs); cl_items.append(ce - cs); wi_items.append(k)
         n_items = len(cs_items)
+        # every index table goes up before the first launch: a pageable upload behind queued kernels would stall the host
         d_cs = hip.to_device(np.asarray(cs_items, np.int64)); d_cl = hip.to_device(np.asarray(cl_items, np.int64))
         d_wi = hip.to_device(np.asarray(wi_items, np.int32))
+        d_chunk_start = hip.to_device(np.asarray([r[0] for r in ranges], np.int64))
+        d_chunk_len = hip.to_device(np.asarray([r[1] - r[0] for r in ranges], np.int64))
+        d_es = hip.to_device(np.asarray([r[2] for r in ranges], np.int64)); d_ee = hip.to_device(np.asarray([r[3] for r in ranges], np.int64))
+        d_base = hip.to_device(np.asarray(base, np.int32))
+        offsets = np.concatenate(([0], np.cumsum([r[1] - r[0] for r in ranges]))).astype(np.int64)
+        d_offsets = hip.to_device(offsets[:-1])
         wave = torch.empty((n_items, 2, ITEM_LEN), dtype=torch.float32, device=hip.device)
         step = max(1, self.max_items_per_forward)
         events: List[List[torch.cuda.Event]] = []     # per sub-batch: [before stft, before net, before istft, after istft]
@@ -210,13 +220,8 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             if ev:
                 ev[3].record()
                 events.append(ev)
-        d_chunk_start = hip.to_device(np.asarray([r[0] for r in ranges], np.int64))
-        d_chunk_len = hip.to_device(np.asarray([r[1] - r[0] for r in ranges], np.int64))
-        d_es = hip.to_device(np.asarray([r[2] for r in ranges], np.int64)); d_ee = hip.to_device(np.asarray([r[3] for r in ranges], np.int64))
-        d_base = hip.to_device(np.asarray(base, np.int32))
         vocal_like, other = hip.mdx_assemble_ola(track_dev, wave, d_chunk_start, d_chunk_len, d_es, d_ee, d_base)
-        offsets = np.concatenate(([0], np.cumsum([r[1] - r[0] for r in ranges]))).astype(np.int64)
-        chunk_vocal = hip.mdx_chunk_vocal(wave, d_chunk_len, hip.to_device(offsets[:-1]), d_base, int(offsets[-1]))
+        chunk_vocal = hip.mdx_chunk_vocal(wave, d_chunk_len, d_offsets, d_base, int(offsets[-1]))
         if self.get_output_type() == "vocal":
             vocal, inst = vocal_like, other
         else:
@@ -224,17 +229,24 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             vocal, inst = other, vocal_like
             chunk_mix = torch.cat([track_dev[cs:ce] for cs, ce, _, _ in ranges])
             chunk_vocal = chunk_mix - chunk_vocal
-        t_stft = t_net = t_istft = 0.0
-        if events:                 # one synchronisation for the whole track, after everything has been queued
-            events[-1][3].synchronize()
-            for ev in events:
-                t_stft += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_istft += ev[2].elapsed_time(ev[3])
-        self._perf["chunks"] += float(len(ranges))
-        self._perf["compute_ms"] += t_stft + t_net + t_istft
-        self._perf["max_alloc_bytes"] = max(self._perf["max_alloc_bytes"], float(torch.cuda.max_memory_allocated(hip.device)))
-        if timings is not None:
-            timings.update({"stft_ms": t_stft, "unet_ms": t_net, "istft_ms": t_istft, "n_items": float(n_items)})
-        return TrackSeparation(vocal, inst, chunk_vocal, [int(o) for o in offsets[:-1]], ranges, n_items)
+        n_ranges = len(ranges)
+
+        def finish() -> None:      # one synchronisation for the whole track, after everything has been queued
+            t_stft = t_net = t_istft = 0.0
+            if events:
+                events[-1][3].synchronize()
+                for ev in events:
+                    t_stft += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_istft += ev[2].elapsed_time(ev[3])
+            self._perf["chunks"] += float(n_ranges)
+            self._perf["compute_ms"] += t_stft + t_net + t_istft
+            self._perf["max_alloc_bytes"] = max(self._perf["max_alloc_bytes"], float(torch.cuda.max_memory_allocated(hip.device)))
+            if timings is not None:
+                timings.update({"stft_ms": t_stft, "unet_ms": t_net, "istft_ms": t_istft, "n_items": float(n_items)})
+
+        if not defer_sync:
+            finish()
+        return TrackSeparation(vocal, inst, chunk_vocal, [int(o) for o in offsets[:-1]], ranges, n_items,
+                               finish if defer_sync else None)
 
     # -- reference-shaped per-chunk call ----------------------------------------------------------
     def infer_chunk(self, mix_chunk: np.ndarray, **kwargs) -> SeparationOutputs:
