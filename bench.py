@@ -94,6 +94,45 @@ def roofline_conv(probe, conv_ms: float, conv_flops: float, elapsed: float) -> d
     }
 
 
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
+
+
+def framewise_rooflines(hip, mix_dev, reps: int = 5) -> list:
+    """the framewise / scan kernels are HBM-bound streaming passes; report achieved GB/s per kernel on the
+    C2 track (algorithmic bytes per launch / HIP-event time on the launch stream), outside the timed region."""
+    n = int(mix_dev.numel())
+
+    def timed(fn) -> float:
+        fn()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    rows = []
+
+    def add(name, fn, nbytes):
+        ms = timed(fn)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append({"kernel": name, "bytes": int(nbytes), "ms": round(ms, 4), "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+
+    for frame, hop in ((4410, 2205), (2048, 441), (2205, 882), (1102, 441)):
+        nf = 1 + n // hop
+        add(f"ac_frame_rms({frame},{hop})", lambda f=frame, h=hop: hip.frame_rms(mix_dev, f, h), 4 * n + 4 * nf)
+    add("ac_stft2048_features(hop 441, flatness)", lambda: hip.stft2048_features(mix_dev, 441, want_flat=True, want_mel=False),
+        4 * n + 4 * (1 + n // 441))
+    add("ac_stft2048_features(hop 512, mel-128)", lambda: hip.stft2048_features(mix_dev, 512, want_flat=False, want_mel=True),
+        4 * n + 512 * (1 + n // 512))
+    _, mel = hip.stft2048_features(mix_dev, 512, want_flat=False, want_mel=True)
+    add("ac_onset_strength(mean)", lambda: hip.onset_strength(mel, 512, "mean"), 2 * 512 * mel.shape[0] + 4 * mel.shape[0])
+    add("ac_moving_meansq_db_f64(W 3528)", lambda: hip.moving_meansq_db(mix_dev, 3528), 12 * n)
+    db = hip.moving_meansq_db(mix_dev, 3528)
+    add("ac_next_leq_scan", lambda: hip.next_leq_scan(db, -40.0), 16 * n)
+    return rows
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +245,8 @@ def main() -> None:
             "n_boundaries": all_summaries[0]["n_boundaries"], "boundaries_sha1": all_summaries[0]["boundaries_sha1"],
             "tracks_completed": len(all_summaries),
         }
+        if world == 1:
+            out["framewise_rooflines"] = framewise_rooflines(hip, mix_dev)
         if world == 1 and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds, weights, spec)
         print(json.dumps(out))
