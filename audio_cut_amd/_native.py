@@ -81,6 +81,12 @@ SIGNATURES = {
     "ac_conv1x1_small": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I64, _I, _P]),
     "ac_down2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P]),
     "ac_up2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P]),
+    "ac_pyin_observe": (C.c_int, [_P, _P, _I64, _I, _I, C.c_double, C.c_double, _I, _I, _P, _P, _P, _P, _P, C.c_double, C.c_double,
+                                  _P, _P, _P, _P]),
+    "ac_pyin_viterbi": (C.c_int, [_P, _P, _P, _I64, _I, _I, _P, _P, C.c_double, _P, _P, _P, _P]),
+    "ac_lpc_formants": (C.c_int, [_P, _P, _I64, _I, _I, _I, C.c_float, _P, _P, _I64, _P]),
+    "ac_zero_crossing_rate": (C.c_int, [_P, _P, _I64, _I, _I, _P, _I64, _P]),
+    "ac_stft2048_spectral": (C.c_int, [_P, _P, _I64, _I, C.c_double, _P, _P, _I64, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -211,10 +217,116 @@ class Context:
         max_period = min(int(np.ceil(sr / fmin)), frame_length - frame_length // 2 - 1)
         nf = 1 + n // hop
         period = torch.empty(nf, dtype=torch.float64, device=self.device)
-        cmnd = torch.empty((nf, max_period - min_period + 1), dtype=torch.float32, device=self.device) if want_cmnd else None
+        cmnd = torch.empty((nf, max_period - min_period + 1), dtype=torch.float64, device=self.device) if want_cmnd else None
         _check(self.lib.ac_yin_f0(self._h, _ptr(x), n, frame_length, hop, min_period, max_period, float(threshold),
                                   _ptr(period), _ptr(cmnd), nf, _stream()))
         return float(sr) / period.cpu().numpy(), cmnd
+
+    # -- multi-feature detector branch ---------------------------------------------
+    _PYIN_TABLES = None
+
+    @classmethod
+    def _pyin_tables(cls):
+        """Host tables of librosa.pyin (numpy / scipy values so the kernel's products are the ones librosa forms)."""
+        if cls._PYIN_TABLES is None:
+            import scipy.stats
+            thresholds = np.linspace(0, 1, 101)
+            beta_probs = np.diff(scipy.stats.beta.cdf(thresholds, 2, 18))
+            beta_cum = np.array([np.sum(beta_probs[:k]) for k in range(101)], dtype=np.float64)
+            nn = np.arange(0, 513, dtype=np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                fact = (1.0 - np.exp(-2.0)) / (1.0 - np.exp(-2.0 * nn))
+            fact[0] = 0.0
+            ek = np.exp(-2.0 * np.arange(0, 512, dtype=np.float64))
+            cls._PYIN_TABLES = (thresholds, beta_probs, beta_cum, fact, ek)
+        return cls._PYIN_TABLES
+
+    def pyin(self, x: torch.Tensor, sr: int, fmin: float, fmax: float, frame_length: int = 2048, hop: Optional[int] = None,
+             resolution: float = 0.1, max_transition_rate: float = 35.92, switch_prob: float = 0.01, no_trough_prob: float = 0.01):
+        """librosa.pyin on the GPU -> (f0 [frames] float64 with NaN where unvoiced, voiced_flag, voiced_prob), host arrays.
+        CMND curves (ac_yin_f0) -> trough probabilities / pitch-bin observations (ac_pyin_observe) -> Viterbi (ac_pyin_viterbi)."""
+        import scipy.signal
+        self._chk_f32(x)
+        hop = frame_length // 4 if hop is None else int(hop)
+        n = x.numel()
+        _, cmnd = self.yin_f0(x, sr, fmin, fmax, frame_length, hop, want_cmnd=True)
+        nf, n_lags = cmnd.shape
+        min_period = max(int(np.floor(sr / fmax)), 1)
+        bps = int(np.ceil(1.0 / resolution))
+        n_bins = int(np.floor(12 * bps * np.log2(fmax / fmin))) + 1
+        thresholds, beta_probs, beta_cum, fact, ek = self._pyin_tables()
+        tiny = float(np.finfo(np.float64).tiny)
+        d = lambda a: self.to_device(np.ascontiguousarray(a, dtype=np.float64))
+        logv = torch.empty((nf, n_bins), dtype=torch.float64, device=self.device)
+        logu = torch.empty(nf, dtype=torch.float64, device=self.device)
+        vp = torch.empty(nf, dtype=torch.float64, device=self.device)
+        tabs = [d(thresholds), d(beta_probs), d(beta_cum), d(fact), d(ek)]     # keep the device tables alive across the launch
+        _check(self.lib.ac_pyin_observe(self._h, _ptr(cmnd), nf, n_lags, min_period, float(sr), float(fmin), n_bins, bps,
+                                        _ptr(tabs[0]), _ptr(tabs[1]), _ptr(tabs[2]), _ptr(tabs[3]), _ptr(tabs[4]),
+                                        float(no_trough_prob), tiny, _ptr(logv), _ptr(logu), _ptr(vp), _stream()))
+        # banded log-transition tables, built exactly like librosa.sequence.transition_local(window="triangle", wrap=False)
+        max_semitones = round(max_transition_rate * 12 * hop / sr)
+        width = max_semitones * bps + 1
+        half = width // 2
+        win = scipy.signal.get_window("triangle", width, fftbins=False)
+        base = np.zeros(n_bins)
+        lpad = (n_bins - width) // 2
+        base[lpad: lpad + width] = win
+        dense = np.zeros((n_bins, n_bins))
+        for i in range(n_bins):                       # same steps (pad_center, roll, clip, row-normalise) as librosa: same rounding
+            row = np.roll(base, n_bins // 2 + i + 1)
+            row[min(n_bins, i + width // 2 + 1):] = 0
+            row[: max(0, i - width // 2)] = 0
+            dense[i] = row
+        dense /= dense.sum(axis=1, keepdims=True)
+        idx = np.arange(n_bins)
+        src = idx[:, None] - half + np.arange(width)[None, :]                  # per DESTINATION j, tap d <-> source i = j - half + d
+        ok = (src >= 0) & (src < n_bins)
+        t_in = np.where(ok, dense[np.clip(src, 0, n_bins - 1), idx[:, None]], 0.0)
+        lt_same = np.log((1 - switch_prob) * t_in + tiny)
+        lt_cross = np.log(switch_prob * t_in + tiny)
+        p_init = np.zeros(2 * n_bins); p_init[n_bins:] = 1 / n_bins
+        ptr = torch.empty((nf, 2 * n_bins), dtype=torch.int16, device=self.device)
+        states = torch.empty(nf, dtype=torch.int32, device=self.device)
+        vt = [d(lt_same), d(lt_cross), d(np.log(p_init + tiny))]
+        _check(self.lib.ac_pyin_viterbi(self._h, _ptr(logv), _ptr(logu), nf, n_bins, half, _ptr(vt[0]), _ptr(vt[1]),
+                                        float(np.log(tiny)), _ptr(vt[2]), _ptr(ptr), _ptr(states), _stream()))
+        st = states.cpu().numpy().astype(np.int64)
+        freqs = fmin * 2 ** (np.arange(n_bins) / (12 * bps))
+        f0 = freqs[st % n_bins]
+        voiced = st < n_bins
+        f0 = f0.copy(); f0[~voiced] = np.nan
+        return f0, voiced, vp.cpu().numpy()
+
+    def lpc_formants(self, x: torch.Tensor, frame_len: int, hop: int, order: int = 12, preemph: float = 0.95):
+        """`_extract_formants`: per-frame LPC peak magnitudes -> (count [frames] int32, mags [frames, 3] float64), host arrays."""
+        self._chk_f32(x)
+        n = x.numel()
+        nf = len(range(0, n - frame_len, hop))
+        if nf <= 0:
+            return np.zeros(0, np.int32), np.zeros((0, 3), np.float64)
+        cnt = torch.empty(nf, dtype=torch.int32, device=self.device)
+        mag = torch.empty((nf, 3), dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_lpc_formants(self._h, _ptr(x), n, frame_len, hop, order, float(preemph), _ptr(cnt), _ptr(mag), nf, _stream()))
+        return cnt.cpu().numpy(), mag.cpu().numpy()
+
+    def zero_crossing_rate(self, x: torch.Tensor, frame_len: int, hop: int) -> np.ndarray:
+        self._chk_f32(x)
+        n = x.numel()
+        nf = 1 + n // hop
+        out = torch.empty(nf, dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_zero_crossing_rate(self._h, _ptr(x), n, frame_len, hop, _ptr(out), nf, _stream()))
+        return out.cpu().numpy()
+
+    def stft2048_spectral(self, x: torch.Tensor, sr: int, hop: int):
+        """(spectral centroid float64 [frames], low-third magnitude ratio float32 [frames]), host arrays."""
+        self._chk_f32(x)
+        n = x.numel()
+        nf = 1 + n // hop
+        cen = torch.empty(nf, dtype=torch.float64, device=self.device)
+        rat = torch.empty(nf, dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_stft2048_spectral(self._h, _ptr(x), n, hop, float(sr), _ptr(cen), _ptr(rat), nf, _stream()))
+        return cen.cpu().numpy(), rat.cpu().numpy()
 
     # -- guard ---------------------------------------------------------------------------------------
     def moving_meansq_db(self, x: torch.Tensor, win: int) -> torch.Tensor:

@@ -173,6 +173,67 @@ extern "C" int ac_stft2048_features(ac_ctx* ctx, const float* x, int64_t n, int 
     return AC_OK;
 }
 
+// Spectral centroid and low-third magnitude ratio per frame (the multi-feature detector branch):
+//   centroid = sum_k f_k * float32(S_k / sum_k S_k)           (librosa.feature.spectral_centroid; `normalize` measures
+//              the column in float64 and stores S / length back as float32)
+//   ratio    = low / ((low + high) + 1e-10), low = sum S[:1025 // 3], high = the rest, float32
+//              (`_calculate_harmonic_ratio_direct`, pure_vocal_pause_detector.py:936-957)
+__global__ __launch_bounds__(256) void k_stft2048_spectral(const float* __restrict__ x, int64_t n, int hop, double sr,
+                                                           const double2* __restrict__ tw, const double* __restrict__ hann,
+                                                           double* __restrict__ centroid_out, float* __restrict__ ratio_out) {
+    __shared__ double2 s_a[1024];
+    __shared__ double2 s_b[1024];
+    __shared__ float s_m[1025];
+    __shared__ double s_red[12];
+    const int64_t f = blockIdx.x;
+    const int64_t s0 = f * (int64_t)hop - 1024;
+    for (int m = threadIdx.x; m < 1024; m += 256) {
+        const int64_t g0 = s0 + 2 * m, g1 = g0 + 1;
+        const double a0 = (g0 >= 0 && g0 < n) ? (double)x[g0] : 0.0;
+        const double a1 = (g1 >= 0 && g1 < n) ? (double)x[g1] : 0.0;
+        s_a[m] = make_double2(a0 * hann[2 * m], a1 * hann[2 * m + 1]);
+    }
+    __syncthreads();
+    const double2* Z = fft1024_f64(s_a, s_b, tw);
+    for (int k = threadIdx.x; k <= 1024; k += 256) {
+        const double2 zk = Z[k & 1023];
+        const double2 zn = Z[(1024 - k) & 1023];
+        const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+        const double2 o = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y + zn.y));
+        double2 w = (k < 1024) ? tw[k] : make_double2(-1.0, 0.0);
+        const double2 wo = cmul(w, o);
+        const float re32 = (float)(e.x + wo.y), im32 = (float)(e.y - wo.x);     // complex64 storage, then np.abs
+        s_m[k] = (float)sqrt((double)re32 * (double)re32 + (double)im32 * (double)im32);
+    }
+    __syncthreads();
+    double tot = 0.0, low = 0.0;
+    for (int k = threadIdx.x; k <= 1024; k += 256) { const double v = (double)s_m[k]; tot += v; if (k < 1025 / 3) low += v; }
+    const double length = block_sum_f64_256(tot, s_red);
+    const double lowsum = block_sum_f64_256(low, s_red + 4);
+    const double len_eff = length < 1.17549435e-38 ? 1.0 : length;
+    double c = 0.0;
+    for (int k = threadIdx.x; k <= 1024; k += 256) {
+        const float sn = (float)((double)s_m[k] / len_eff);
+        c += ((double)k * sr / 2048.0) * (double)sn;
+    }
+    const double csum = block_sum_f64_256(c, s_red + 8);
+    if (threadIdx.x == 0) {
+        centroid_out[f] = csum;
+        const float lo32 = (float)lowsum, hi32 = (float)(length - lowsum);
+        ratio_out[f] = lo32 / ((lo32 + hi32) + 1e-10f);
+    }
+}
+
+extern "C" int ac_stft2048_spectral(ac_ctx* ctx, const float* x, int64_t n, int hop, double sr, double* centroid_out, float* ratio_out,
+                                     int64_t n_frames, void* stream) {
+    AC_REQUIRE(ctx && x && centroid_out && ratio_out, "null pointer");
+    AC_REQUIRE(n > 0 && hop > 0 && n_frames == 1 + n / hop && n_frames < (1LL << 31), "n_frames != 1 + n/hop");
+    hipLaunchKernelGGL(k_stft2048_spectral, dim3((unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, x, n, hop, sr, ctx->tw2048,
+                       ctx->hann2048, centroid_out, ratio_out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
 // =================================================================================================
 // Onset strength from mel power: dB (float32 like librosa.power_to_db), per-group top_db clip,
 // lag-1 positive difference, mean / median over the 128 bands, librosa's left padding.
@@ -376,12 +437,16 @@ extern "C" int ac_tempogram_reduce(ac_ctx* ctx, const float* env, int64_t n, int
 
 __global__ __launch_bounds__(256) void k_yin(const float* __restrict__ x, int64_t n, int frame_length, int hop,
                                              int min_period, int max_period, double threshold,
-                                             double* __restrict__ period_out, float* __restrict__ cmnd_out) {
+                                             double* __restrict__ period_out, double* __restrict__ cmnd_out) {
+    // Precision follows librosa under the reference's pinned numpy (< 2): np.fft works in double, so the
+    // autocorrelation is float64, while the windowed energies come from a float32 np.cumsum of the squared frame
+    // (sequential float32 adds, reproduced here on one thread); yin = e[0] + e[tau] - 2 acf and everything after it
+    // is float64 (tiny = float64's).
     extern __shared__ double s_dyn[];
     double* s_x = s_dyn;                               // frame_length
-    double* s_cs = s_x + frame_length;                 // frame_length + 1 (exclusive prefix of squares)
-    double* s_yin = s_cs + frame_length + 1;           // max_period + 1
+    double* s_yin = s_x + frame_length;                // max_period + 1
     double* s_cm = s_yin + (max_period + 1);           // max_period + 1 (cmnd, index by tau)
+    float* s_cs = reinterpret_cast<float*>(s_cm + (max_period + 1));   // frame_length: inclusive float32 cumsum of x^2
     __shared__ double s_red[4];
     __shared__ double s_scan[4];
     __shared__ long long s_idx[4];
@@ -393,73 +458,36 @@ __global__ __launch_bounds__(256) void k_yin(const float* __restrict__ x, int64_
         s_x[i] = (g >= 0 && g < n) ? (double)x[g] : 0.0;
     }
     __syncthreads();
-    // exclusive prefix sums of squares: cs[k] = sum_{j<k} x_j^2   (contiguous chunk per thread + block scan)
-    {
-        const int per = (frame_length + 255) / 256;
-        const int e0 = threadIdx.x * per;
-        double loc = 0.0;
-        for (int q = 0; q < per; ++q) { const int e = e0 + q; if (e < frame_length) loc += s_x[e] * s_x[e]; }
-        // block exclusive scan of `loc`
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        double inc = loc;
-        for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(inc, off, AC_WAVE); if (lane >= off) inc += t; }
-        if (lane == 63) s_scan[w] = inc;
-        __syncthreads();
-        double base = 0.0;
-        for (int q = 0; q < w; ++q) base += s_scan[q];
-        const double prev = __shfl_up(inc, 1, AC_WAVE);
-        double run = base + (lane > 0 ? prev : 0.0);
-        for (int q = 0; q < per; ++q) {
-            const int e = e0 + q;
-            if (e < frame_length) { s_cs[e] = run; run += s_x[e] * s_x[e]; }
-        }
-        if (e0 < frame_length && e0 + per >= frame_length) s_cs[frame_length] = run;   // total, written by the thread owning the last chunk
+    if (threadIdx.x == 0) {
+        float run = 0.f;
+        for (int i = 0; i < frame_length; ++i) { const float v = (float)s_x[i]; run = run + v * v; s_cs[i] = run; }
     }
     __syncthreads();
-    // difference function for tau = 0 .. max_period
-    const double e_zero_raw = s_cs[W + 1] - s_cs[1];
-    const double e_zero = fabs(e_zero_raw) < 1e-6 ? 0.0 : e_zero_raw;
+    // difference function for tau = 0 .. max_period: energy[tau] = cs[tau + W] - cs[tau] (float32), acf in float64
+    float e0 = s_cs[W] - s_cs[0];
+    if (fabsf(e0) < 1e-6f) e0 = 0.f;
     for (int tau = threadIdx.x; tau <= max_period; tau += 256) {
         double acf = 0.0;
         for (int j = 1; j <= W; ++j) acf += s_x[j] * s_x[j + tau];
         if (fabs(acf) < 1e-6) acf = 0.0;
-        double e = s_cs[tau + W + 1] - s_cs[tau + 1];
-        if (fabs(e) < 1e-6) e = 0.0;
-        s_yin[tau] = e_zero + e - 2.0 * acf;
+        float e = s_cs[tau + W] - s_cs[tau];
+        if (fabsf(e) < 1e-6f) e = 0.f;
+        s_yin[tau] = (double)(e0 + e) - 2.0 * acf;     // float32 + float32, then float64 with the autocorrelation
     }
     __syncthreads();
-    // cumulative mean over tau = 1 .. max_period, then cmnd[tau] = yin[tau] / (cm[tau] + tiny_f32)
-    {
-        const int per = (max_period + 255) / 256;
-        const int t0 = 1 + threadIdx.x * per;
-        double loc = 0.0;
-        for (int q = 0; q < per; ++q) { const int t = t0 + q; if (t <= max_period) loc += s_yin[t]; }
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        double inc = loc;
-        for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(inc, off, AC_WAVE); if (lane >= off) inc += t; }
-        __syncthreads();
-        if (lane == 63) s_scan[w] = inc;
-        __syncthreads();
-        double base = 0.0;
-        for (int q = 0; q < w; ++q) base += s_scan[q];
-        const double prev = __shfl_up(inc, 1, AC_WAVE);
-        double run = base + (lane > 0 ? prev : 0.0);
-        for (int q = 0; q < per; ++q) {
-            const int t = t0 + q;
-            if (t <= max_period) {
-                run += s_yin[t];
-                // librosa holds these series in float32: round numerator and denominator there
-                const float num = (float)s_yin[t];
-                const float den = (float)(run / (double)t);
-                s_cm[t] = (double)(num / (den + 1.17549435e-38f));
-            }
+    // cumulative mean over tau = 1 .. max_period (np.cumsum: sequential float64), cmnd[tau] = yin[tau] / (cm[tau] + tiny)
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int t = 1; t <= max_period; ++t) {
+            run += s_yin[t];
+            s_cm[t] = s_yin[t] / (run / (double)t + 2.2250738585072014e-308);
         }
     }
     __syncthreads();
     const int n_lags = max_period - min_period + 1;
     if (cmnd_out) {
-        float* row = cmnd_out + f * (int64_t)n_lags;
-        for (int i = threadIdx.x; i < n_lags; i += 256) row[i] = (float)s_cm[min_period + i];
+        double* row = cmnd_out + f * (int64_t)n_lags;
+        for (int i = threadIdx.x; i < n_lags; i += 256) row[i] = s_cm[min_period + i];
     }
     // first trough below the threshold, else the first global minimum (indices relative to min_period)
     long long first = NQ_INF_I;
@@ -489,18 +517,17 @@ __global__ __launch_bounds__(256) void k_yin(const float* __restrict__ x, int64_
         const long long pick = (fi != NQ_INF_I) ? fi : gi;
         double shift = 0.0;
         if (pick > 0 && pick < n_lags - 1) {
-            // float32 arithmetic like librosa's parabolic interpolation on the float32 cmnd
-            const float xm = (float)s_cm[min_period + pick - 1], x0 = (float)s_cm[min_period + pick], xp = (float)s_cm[min_period + pick + 1];
-            const float a = xp + xm - 2.0f * x0;
-            const float b = (xp - xm) / 2.0f;
-            if (!(fabsf(b) >= fabsf(a))) shift = (double)(-b / a);
+            const double xm = s_cm[min_period + pick - 1], x0 = s_cm[min_period + pick], xp = s_cm[min_period + pick + 1];
+            const double a = xp + xm - 2.0 * x0;
+            const double b = (xp - xm) / 2.0;
+            if (!(fabs(b) >= fabs(a))) shift = -b / a;
         }
         period_out[f] = (double)min_period + (double)pick + shift;
     }
 }
 
 extern "C" int ac_yin_f0(ac_ctx* ctx, const float* x, int64_t n, int frame_length, int hop, int min_period, int max_period,
-                         double threshold, double* period_out, float* cmnd_out, int64_t n_frames, void* stream) {
+                         double threshold, double* period_out, double* cmnd_out, int64_t n_frames, void* stream) {
     AC_REQUIRE(ctx && x && period_out, "null pointer");
     AC_REQUIRE(n > 0 && hop > 0 && frame_length >= 4 && frame_length <= YIN_MAX_FRAME && (frame_length % 2) == 0, "frame_length in [4, 4096], even");
     AC_REQUIRE(min_period >= 1 && max_period > min_period + 1 && max_period <= frame_length - frame_length / 2 - 1 && max_period < YIN_MAX_LAGS,

@@ -69,6 +69,18 @@ def _clamp(v, lo, hi):
     return max(lo, min(hi, v))
 
 
+@dataclass
+class VocalFeatures:
+    """`pure_vocal_pause_detector.py:39-48` (same field names and order)."""
+    f0_contour: np.ndarray
+    f0_confidence: np.ndarray
+    formant_energies: List[np.ndarray]
+    spectral_centroid: np.ndarray
+    harmonic_ratio: np.ndarray
+    zero_crossing_rate: np.ndarray
+    rms_energy: np.ndarray
+
+
 @dataclass(frozen=True)
 class AdaptStats:
     bpm: Optional[float] = None
@@ -165,11 +177,16 @@ class PureVocalPauseDetector:
             # yields no speech segments and therefore no focus restriction
             focus = []
         self._last_focus_windows = list(focus or [])
-        if not get_config("pure_vocal_detection.enable_relative_energy_mode", False):
-            raise NotImplementedError("multi-feature (pyin/LPC) branch is dormant under the live configuration "
-                                      "(config/expert.yaml:38) and not built in this round")
         vocal_dev = self._dev(vocal_audio, vocal_dev)
         n = int(vocal_dev.numel())
+        if not get_config("pure_vocal_detection.enable_relative_energy_mode", False):
+            # the multi-feature branch (`:268-281`; dormant under config/expert.yaml:38)
+            pauses = self._detect_multifeature(vocal_dev, include_breath_candidates)
+            if enable_mdd_enhancement and (original_audio is not None or original_dev is not None or cache is not None):
+                pauses = self._apply_mdd_enhancement(pauses, original_audio, cache, focus, original_dev=original_dev)
+            if pauses:
+                pauses = self._calculate_precise_cut_points(pauses, vocal_dev)
+            return pauses
 
         tempo: Optional[float]
         if cache is not None and cache.bpm_features is not None:
@@ -209,6 +226,141 @@ class PureVocalPauseDetector:
         if pauses:
             pauses = self._calculate_precise_cut_points(pauses, vocal_dev)
         return pauses
+
+    # ---- multi-feature branch ------------------------------------------------
+    def _extract_vocal_features(self, vocal_dev) -> "VocalFeatures":
+        """`_extract_vocal_features` (`:410-459`): every series comes from a HIP kernel on the resident vocal
+        (ac_yin_f0 -> ac_pyin_observe -> ac_pyin_viterbi, ac_lpc_formants, ac_stft2048_spectral, ac_zero_crossing_rate,
+        ac_frame_rms); the host only assembles the formant tracks with the reference's append rule (`:1003-1012`)."""
+        ctx = self._context()
+        sr, hop = self.sample_rate, self.hop_length
+        c2 = 440.0 * 2.0 ** ((36 - 69) / 12.0)        # librosa.note_to_hz('C2'), 'C7' (`:422-425`)
+        c7 = 440.0 * 2.0 ** ((96 - 69) / 12.0)
+        f0, _, voiced_prob = ctx.pyin(vocal_dev, sr, c2, c7, frame_length=2048, hop=hop)
+        cnt, mag = ctx.lpc_formants(vocal_dev, int(0.025 * sr), hop, order=12, preemph=0.95)
+        tracks = []
+        for j in range(3):
+            # a frame with peaks appends to tracks 0..min(3, peaks)-1 only; a frame without peaks appends 0.0 to all three
+            keep = (cnt == 0) | (cnt > j)
+            tracks.append(np.where(cnt[keep] == 0, 0.0, mag[keep, j]))
+        centroid, ratio = ctx.stft2048_spectral(vocal_dev, sr, hop)
+        zcr = ctx.zero_crossing_rate(vocal_dev, 2048, hop)
+        rms = ctx.frame_rms(vocal_dev, 2048, hop).cpu().numpy()
+        return VocalFeatures(f0_contour=f0, f0_confidence=voiced_prob, formant_energies=tracks, spectral_centroid=centroid,
+                             harmonic_ratio=ratio, zero_crossing_rate=zcr, rms_energy=rms)
+
+    def _detect_candidate_pauses(self, ft: "VocalFeatures") -> List[Tuple[int, int]]:
+        """`:618-682`."""
+        from scipy.ndimage import gaussian_filter1d
+        sr, hop = self.sample_rate, self.hop_length
+        if get_config("pure_vocal_detection.enable_relative_energy_mode", False):
+            peak = np.max(ft.rms_energy); avg = np.mean(ft.rms_energy)
+            thr = min(peak * get_config("pure_vocal_detection.peak_relative_threshold_ratio", 0.1),
+                      avg * get_config("pure_vocal_detection.rms_relative_threshold_ratio", 0.2))
+            low_energy = ft.rms_energy < thr
+        else:
+            r = np.abs(ft.rms_energy)                                  # librosa.amplitude_to_db(rms, ref=np.max), top_db 80
+            power = np.square(r)
+            db = 10.0 * np.log10(np.maximum(1e-10, power))
+            db -= 10.0 * np.log10(np.maximum(1e-10, np.max(r) ** 2))
+            db = np.maximum(db, db.max() - 80.0)
+            low_energy = db < get_config("pure_vocal_detection.energy_threshold_db", -40)
+        f0_missing = ft.f0_confidence < get_config("pure_vocal_detection.f0_drop_threshold", 0.7)
+        frames = gaussian_filter1d((low_energy & f0_missing).astype(float), sigma=3) > 0.5
+        min_dur = get_config("pure_vocal_detection.breath_duration_range", [0.1, 0.3])[0]
+        edges = np.flatnonzero(np.diff(np.concatenate(([False], frames, [False])).astype(np.int8)))
+        return [(int(a), int(b)) for a, b in zip(edges[0::2], edges[1::2]) if (b - a) * hop / sr >= min_dur]
+
+    def _pause_interval_features(self, ft: "VocalFeatures", s: int, e: int) -> Dict:
+        """`:733-806`."""
+        import warnings
+        ctx_frames = int(0.5 * self.sample_rate / self.hop_length)
+        pre = max(0, s - ctx_frames); post = min(len(ft.rms_energy), e + ctx_frames)
+        f0_drop = 0.0
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            if pre < s:
+                pre_f0 = np.nanmean(ft.f0_contour[pre:s]); pause_f0 = np.nanmean(ft.f0_contour[s:e])
+                if not np.isnan(pre_f0) and not np.isnan(pause_f0) and pre_f0 > 0:
+                    f0_drop = 1.0 - (pause_f0 / pre_f0)
+            pre_e = np.mean(ft.rms_energy[pre:s]) if pre < s else 0
+            pause_e = np.mean(ft.rms_energy[s:e])
+            post_e = np.mean(ft.rms_energy[e:post]) if e < post else 0
+            energy_drop = (pre_e - pause_e) / (pre_e + 1e-10)
+            energy_rise = (post_e - pause_e) / (pause_e + 1e-10)
+            centroid_shift = 0.0; harmonic_drop = 0.0
+            if pre < s:
+                pc = np.mean(ft.spectral_centroid[pre:s]); qc = np.mean(ft.spectral_centroid[s:e])
+                centroid_shift = abs(pc - qc) / (pc + 1e-10)
+                ph = np.mean(ft.harmonic_ratio[pre:s]); qh = np.mean(ft.harmonic_ratio[s:e])
+                harmonic_drop = (ph - qh) / (ph + 1e-10)
+            stab = []
+            for tr in ft.formant_energies:
+                if len(tr) > e:
+                    seg = tr[s:e]
+                    stab.append(1.0 - (np.std(seg) / (np.mean(seg) + 1e-10)))
+        return {"f0_drop_rate": f0_drop, "energy_drop": energy_drop, "energy_rise": energy_rise, "centroid_shift": centroid_shift,
+                "harmonic_drop": harmonic_drop, "formant_stability": np.mean(stab) if stab else 0.5,
+                "pre_energy": pre_e, "pause_energy": pause_e, "post_energy": post_e}
+
+    def _pause_confidence(self, f: Dict, duration: float) -> float:
+        """`:808-848`."""
+        breath = get_config("pure_vocal_detection.breath_duration_range", [0.1, 0.3])
+        f0_score = min(1.0, f["f0_drop_rate"] / 0.5)
+        energy_score = min(1.0, f["energy_drop"] / 0.7)
+        spectral_score = min(1.0, f["centroid_shift"] / 0.3)
+        if duration < breath[1]:
+            dur_score = 0.3
+        elif duration >= self.min_pause_duration:
+            dur_score = min(1.0, duration / 1.0)
+        else:
+            dur_score = 0.5
+        conf = (get_config("pure_vocal_detection.f0_weight", 0.3) * f0_score
+                + get_config("pure_vocal_detection.formant_weight", 0.25) * (1.0 - f.get("formant_stability", 0.5))
+                + get_config("pure_vocal_detection.spectral_weight", 0.25) * spectral_score
+                + get_config("pure_vocal_detection.duration_weight", 0.2) * dur_score)
+        conf = conf * (0.7 + 0.3 * energy_score)
+        return min(1.0, conf)
+
+    def _detect_multifeature(self, vocal_dev, include_breath_candidates: bool) -> List[PureVocalPause]:
+        """`:268-281`: features -> candidate runs -> per-run scores (`:684-731`) -> classify / filter / merge (`:850-934`)."""
+        sr, hop = self.sample_rate, self.hop_length
+        ft = self._extract_vocal_features(vocal_dev)
+        self._last_vocal_features = ft
+        breath = get_config("pure_vocal_detection.breath_duration_range", [0.1, 0.3])
+        analyzed: List[PureVocalPause] = []
+        for s, e in self._detect_candidate_pauses(ft):
+            st = s * hop / sr; et = e * hop / sr; dur = et - st
+            pf = self._pause_interval_features(ft, s, e)
+            conf = self._pause_confidence(pf, dur)
+            kind = "breath" if dur <= breath[1] else ("true_pause" if dur >= self.min_pause_duration else "uncertain")
+            analyzed.append(PureVocalPause(start_time=st, end_time=et, duration=dur, pause_type=kind, confidence=conf, features=pf))
+        hi = get_config("pure_vocal_detection.pause_confidence_threshold", 0.7)
+        lo = get_config("pure_vocal_detection.breath_filter_threshold", 0.3)
+        kept: List[PureVocalPause] = []
+        for p in analyzed:
+            if p.confidence >= hi:
+                p.pause_type = "true_pause"; kept.append(p)
+            elif p.confidence <= lo:
+                p.pause_type = "breath"
+                if include_breath_candidates:
+                    kept.append(p)
+            elif p.duration >= self.min_pause_duration:
+                p.pause_type = "true_pause"; kept.append(p)
+        if not kept:
+            return kept
+        kept = sorted(kept, key=lambda p: p.start_time)              # `_merge_adjacent_pauses` (`:896-934`), threshold 0.3 s
+        merged: List[PureVocalPause] = []
+        cur = kept[0]
+        for nxt in kept[1:]:
+            if nxt.start_time - cur.end_time <= 0.3:
+                cur = PureVocalPause(start_time=cur.start_time, end_time=nxt.end_time, duration=nxt.end_time - cur.start_time,
+                                     pause_type="true_pause", confidence=max(cur.confidence, nxt.confidence),
+                                     features={**cur.features, **nxt.features})
+            else:
+                merged.append(cur); cur = nxt
+        merged.append(cur)
+        return merged
 
     # ------------------------------------------------------------------------------------------
     def _tempo_of(self, wave_dev) -> float:

@@ -95,3 +95,40 @@ def vocal_like(duration_s: float, seed: int, sr: int = SR) -> np.ndarray:
     voc[0] = song[0]
     voc[1:] = song[1:] - 0.97 * song[:-1]
     return (voc + bed).astype(np.float32)
+
+
+def voice_with_rests(duration_s: float, seed: int, sr: int = SR) -> np.ndarray:
+    """A clean sung line for the multi-feature (pyin / LPC) detector branch: harmonic stacks with vibrato and a
+    formant-like spectral tilt in 1.2-3 s phrases, separated by 0.15-0.9 s rests that hold only a -75 dB noise bed
+    (so rests are > 40 dB below the peak RMS but never exact zeros), plus short breath-like noise puffs in some rests."""
+    rng = np.random.default_rng(seed + 104729)
+    n = int(round(duration_s * sr))
+    t = np.arange(n) / float(sr)
+    out = rng.standard_normal(n) * 1.2e-4
+    pos = int(round(rng.uniform(0.3, 0.8) * sr))
+    edge = int(round(0.020 * sr))
+    ramp = 0.5 - 0.5 * np.cos(np.pi * np.arange(edge) / edge)
+    while pos < n:
+        length = min(int(round(rng.uniform(1.2, 3.0) * sr)), n - pos)
+        if length <= 2 * edge:
+            break
+        note = rng.uniform(130.0, 390.0)
+        f0 = note * (1.0 + 0.010 * np.sin(2 * np.pi * rng.uniform(4.5, 6.5) * t[:length]))
+        phase = 2 * np.pi * np.cumsum(f0) / float(sr)
+        seg = np.zeros(length)
+        for h in range(1, 13):
+            fh = note * h
+            tilt = 1.0 / (1.0 + ((fh - 700.0) / 600.0) ** 2) + 0.4 / (1.0 + ((fh - 1800.0) / 500.0) ** 2) + 0.05
+            seg += tilt * np.sin(h * phase + rng.uniform(0, 2 * np.pi)) / np.sqrt(h)
+        g = np.ones(length)
+        g[:edge] = ramp
+        g[-edge:] = ramp[::-1]
+        out[pos:pos + length] += 0.25 * seg * g / np.max(np.abs(seg))
+        rest = int(round(rng.uniform(0.15, 0.9) * sr))
+        if rest > int(0.5 * sr) and rng.uniform() < 0.5:      # a breath puff inside a long rest
+            b0 = pos + length + int(0.1 * sr)
+            bl = int(0.12 * sr)
+            if b0 + bl < n:
+                out[b0:b0 + bl] += rng.standard_normal(bl) * 0.004 * np.hanning(bl)
+        pos += length + rest
+    return out.astype(np.float32)

@@ -85,9 +85,11 @@ int ac_tempogram_reduce(ac_ctx* ctx, const float* env, int64_t n, int win, const
  * (core/pure_vocal_pause_detector.py:422-428, dormant multi-feature branch): centred frames, difference function
  * over tau in [0, max_period] with W = frame_length/2, cumulative-mean normalisation, first trough below
  * `threshold` (else the global minimum), parabolic refinement.  period_out[n_frames] f64 (f0 = sr / period);
- * cmnd_out[n_frames * (max_period - min_period + 1)] f32 frame-major may be NULL. */
+ * cmnd_out[n_frames * (max_period - min_period + 1)] f64 frame-major may be NULL.  Precision follows librosa under the
+ * reference's pinned numpy < 2: float64 autocorrelation (np.fft works in double there), float32 cumulative-sum
+ * energies, float64 series from the difference function on. */
 int ac_yin_f0(ac_ctx* ctx, const float* x, int64_t n, int frame_length, int hop, int min_period, int max_period,
-              double threshold, double* period_out, float* cmnd_out, int64_t n_frames, void* stream);
+              double threshold, double* period_out, double* cmnd_out, int64_t n_frames, void* stream);
 
 /* ---- quiet guard / cut refinement --------------------------------------------------------- */
 
@@ -222,6 +224,35 @@ int ac_down2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const flo
                     int H, int W, float w_unscale, void* stream);
 int ac_up2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out, int B,
                   int C_in, int C_out, int H, int W, float w_unscale, void* stream);
+
+/* ---- multi-feature detector branch (pure_vocal_pause_detector.py:410-459,937-1018) ----------- */
+
+/* librosa.pyin after the CMND stage (ac_yin_f0's cmnd_out [n_frames][n_lags]): trough probabilities (beta-distributed
+ * thresholds, Boltzmann rank prior, no-trough mass on the global minimum) voted into pitch bins.  Tables come from the
+ * host (numpy / scipy values, so the products are bit-identical to librosa's): thresholds[101] = linspace(0,1,101),
+ * beta_probs[100], beta_cum[n] = sum(beta_probs[:n]), boltz_fact[N] = (1-e^-2)/(1-e^(-2N)), boltz_exp[k] = e^(-2k).
+ * Out: logv [n_frames][n_bins] = log(obs + tiny), logu [n_frames] = log((1 - voiced_prob)/n_bins + tiny), voiced_prob. */
+int ac_pyin_observe(ac_ctx* ctx, const double* cmnd, int64_t n_frames, int n_lags, int min_period, double sr, double fmin, int n_bins,
+                    int bins_per_semitone, const double* thresholds, const double* beta_probs, const double* beta_cum,
+                    const double* boltz_fact, const double* boltz_exp, double no_trough_prob, double tiny_val, double* logv,
+                    double* logu, double* voiced_prob, void* stream);
+/* librosa.sequence.viterbi over the 2*n_bins pitch/voicing states with the banded pyin transition matrix
+ * (lt_same / lt_cross [n_bins][2*half+1] = log(transition + tiny) per destination bin, lt_zero = log(tiny) outside the
+ * band, first-index ties).  ptr_scratch [n_frames][2*n_bins] u16.  states [n_frames] i32. */
+int ac_pyin_viterbi(ac_ctx* ctx, const double* logv, const double* logu, int64_t n_frames, int n_bins, int half,
+                    const double* lt_same, const double* lt_cross, double lt_zero, const double* log_p_init,
+                    unsigned short* ptr_scratch, int* states, void* stream);
+/* `_extract_formants` (pure_vocal_pause_detector.py:959-1018): per frame pre-emphasis, Burg LPC (librosa.lpc), |1/A| on
+ * 512 points, scipy.signal.find_peaks(height = 10 % of max); out_count[f] peaks found, out_mag[f][3] the lowest three. */
+int ac_lpc_formants(ac_ctx* ctx, const float* x, int64_t n, int frame_len, int hop, int order, float preemph, int* out_count,
+                    double* out_mag, int64_t n_frames, void* stream);
+/* librosa.feature.zero_crossing_rate (edge-padded centred frames); out f64 [1 + n/hop]. */
+int ac_zero_crossing_rate(ac_ctx* ctx, const float* x, int64_t n, int frame_len, int hop, double* out, int64_t n_frames,
+                          void* stream);
+/* librosa.feature.spectral_centroid (n_fft 2048) and the low-third magnitude ratio of
+ * `_calculate_harmonic_ratio_direct` (pure_vocal_pause_detector.py:936-957), one STFT pass. */
+int ac_stft2048_spectral(ac_ctx* ctx, const float* x, int64_t n, int hop, double sr, double* centroid_out, float* ratio_out,
+                         int64_t n_frames, void* stream);
 
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 

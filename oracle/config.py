@@ -86,9 +86,21 @@ _CONFIG: Dict[str, Any] = {
 }
 
 _MISSING = object()
+_RUNTIME: Dict[str, Any] = {}
+
+
+def set_runtime_config(overrides: Dict[str, Any]) -> None:
+    """Dotted-key overrides, as the reference's `set_runtime_config` (`config_manager.py:497-509`)."""
+    _RUNTIME.update({str(k): v for k, v in (overrides or {}).items()})
+
+
+def reset_runtime_config() -> None:
+    _RUNTIME.clear()
 
 
 def get_config(path: str, default: Any = None) -> Any:
+    if path in _RUNTIME:
+        return copy.deepcopy(_RUNTIME[path])
     node: Any = _CONFIG
     for part in path.split("."):
         if isinstance(node, dict) and part in node:

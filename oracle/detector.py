@@ -613,3 +613,199 @@ def estimate_confidence(vocal: np.ndarray, inst: Optional[np.ndarray], mix: np.n
         bal = ve / (float(np.mean(np.square(inst))) + 1e-8)
         return float(np.clip(0.5 * ratio + 0.5 * np.clip(bal / (1.0 + bal), 0.0, 1.0), 0.0, 1.0))
     return float(np.clip(ratio, 0.0, 1.0))
+
+
+# --------------------- dormant multi-feature branch ---------------------
+# pure_vocal_pause_detector.py:268-281 when `enable_relative_energy_mode` is false: pyin F0, LPC-12 formant peak
+# magnitudes, spectral centroid, low-third-bin magnitude ratio, ZCR, RMS -> candidate runs -> scored pauses.
+
+@dataclass
+class VocalFeatures:
+    f0_contour: np.ndarray
+    f0_confidence: np.ndarray
+    formant_energies: List[np.ndarray]
+    spectral_centroid: np.ndarray
+    harmonic_ratio: np.ndarray
+    zero_crossing_rate: np.ndarray
+    rms_energy: np.ndarray
+
+
+def extract_formants(audio: np.ndarray, sr: int, hop: int) -> List[np.ndarray]:
+    """`_extract_formants` (`:959-1018`): 25 ms frames, 0.95 pre-emphasis, Burg LPC-12, |1/A| on 512 points,
+    peaks >= 10 % of the maximum, the three lowest-frequency peaks' magnitudes."""
+    import scipy.signal as signal
+    frame_length = int(0.025 * sr)
+    tracks: List[List[float]] = [[], [], []]
+    for i in range(0, len(audio) - frame_length, hop):
+        fr = audio[i:i + frame_length]
+        fr = np.append(fr[0], fr[1:] - 0.95 * fr[:-1])
+        try:
+            a = L.lpc(fr, 12)
+            w, h = signal.freqz(1, a, worN=512, fs=sr)
+            mag = np.abs(h)
+            peaks, _ = signal.find_peaks(mag, height=np.max(mag) * 0.1)
+            if len(peaks) > 0:
+                pm = mag[peaks]                                      # find_peaks returns ascending positions = ascending frequency
+                for j in range(min(3, len(peaks))):
+                    tracks[j].append(float(pm[j]))
+            else:
+                for j in range(3):
+                    tracks[j].append(0.0)
+        except Exception:
+            for j in range(3):
+                tracks[j].append(0.0)
+    return [np.array(t) for t in tracks]
+
+
+def harmonic_ratio_direct(audio: np.ndarray, hop: int) -> np.ndarray:
+    """`_calculate_harmonic_ratio_direct` (`:936-957`): magnitude in the lowest third of the 1025 bins over the total."""
+    mag = np.abs(L.stft(audio, hop_length=hop))
+    nb = mag.shape[0]
+    low = np.sum(mag[:nb // 3, :], axis=0)
+    high = np.sum(mag[nb // 3:, :], axis=0)
+    return low / ((low + high) + 1e-10)
+
+
+def extract_vocal_features(audio: np.ndarray, sr: int) -> VocalFeatures:
+    """`_extract_vocal_features` (`:410-459`)."""
+    hop = int(sr * 0.01)
+    f0, _, vp = L.pyin(audio, L.note_to_hz("C2"), L.note_to_hz("C7"), sr=sr, hop_length=hop)
+    return VocalFeatures(
+        f0_contour=f0, f0_confidence=vp, formant_energies=extract_formants(audio, sr, hop),
+        spectral_centroid=L.spectral_centroid(audio, sr=sr, hop_length=hop)[0],
+        harmonic_ratio=harmonic_ratio_direct(audio, hop),
+        zero_crossing_rate=L.zero_crossing_rate(audio, hop_length=hop)[0],
+        rms_energy=L.rms(audio, hop_length=hop)[0])
+
+
+def detect_candidate_pauses(ft: VocalFeatures, sr: int) -> List[Tuple[int, int]]:
+    """`_detect_candidate_pauses` (`:618-682`) in the absolute-dB mode the dormant branch runs with."""
+    from scipy.ndimage import gaussian_filter1d
+    hop = int(sr * 0.01)
+    if get_config("pure_vocal_detection.enable_relative_energy_mode", False):
+        peak = np.max(ft.rms_energy); avg = np.mean(ft.rms_energy)
+        thr = min(peak * get_config("pure_vocal_detection.peak_relative_threshold_ratio", 0.1),
+                  avg * get_config("pure_vocal_detection.rms_relative_threshold_ratio", 0.2))
+        low_energy = ft.rms_energy < thr
+    else:
+        energy_db = L.amplitude_to_db(ft.rms_energy, ref=np.max)
+        low_energy = energy_db < get_config("pure_vocal_detection.energy_threshold_db", -40)
+    f0_missing = ft.f0_confidence < get_config("pure_vocal_detection.f0_drop_threshold", 0.7)
+    pause_frames = gaussian_filter1d((low_energy & f0_missing).astype(float), sigma=3) > 0.5
+    min_dur = get_config("pure_vocal_detection.breath_duration_range", [0.1, 0.3])[0]
+    out: List[Tuple[int, int]] = []
+    in_pause = False; start = 0
+    for i, is_pause in enumerate(pause_frames):
+        if is_pause and not in_pause:
+            start = i; in_pause = True
+        elif not is_pause and in_pause:
+            if (i - start) * hop / sr >= min_dur:
+                out.append((start, i))
+            in_pause = False
+    if in_pause and (len(pause_frames) - start) * hop / sr >= min_dur:
+        out.append((start, len(pause_frames)))
+    return out
+
+
+def pause_interval_features(ft: VocalFeatures, s: int, e: int, sr: int) -> Dict:
+    """`_extract_pause_interval_features` (`:733-806`)."""
+    hop = int(sr * 0.01)
+    ctx = int(0.5 * sr / hop)
+    pre = max(0, s - ctx); post = min(len(ft.rms_energy), e + ctx)
+    f0_drop = 0.0
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if pre < s:
+                pre_f0 = np.nanmean(ft.f0_contour[pre:s]); pause_f0 = np.nanmean(ft.f0_contour[s:e])
+                if not np.isnan(pre_f0) and not np.isnan(pause_f0) and pre_f0 > 0:
+                    f0_drop = 1.0 - (pause_f0 / pre_f0)
+    pre_e = np.mean(ft.rms_energy[pre:s]) if pre < s else 0
+    pause_e = np.mean(ft.rms_energy[s:e])
+    post_e = np.mean(ft.rms_energy[e:post]) if e < post else 0
+    energy_drop = (pre_e - pause_e) / (pre_e + 1e-10)
+    energy_rise = (post_e - pause_e) / (pause_e + 1e-10)
+    centroid_shift = 0.0; harmonic_drop = 0.0
+    if pre < s:
+        pc = np.mean(ft.spectral_centroid[pre:s]); qc = np.mean(ft.spectral_centroid[s:e])
+        centroid_shift = abs(pc - qc) / (pc + 1e-10)
+        ph = np.mean(ft.harmonic_ratio[pre:s]); qh = np.mean(ft.harmonic_ratio[s:e])
+        harmonic_drop = (ph - qh) / (ph + 1e-10)
+    stab = []
+    for tr in ft.formant_energies:
+        if len(tr) > e:
+            seg = tr[s:e]
+            stab.append(1.0 - (np.std(seg) / (np.mean(seg) + 1e-10)))
+    return {"f0_drop_rate": f0_drop, "energy_drop": energy_drop, "energy_rise": energy_rise, "centroid_shift": centroid_shift,
+            "harmonic_drop": harmonic_drop, "formant_stability": np.mean(stab) if stab else 0.5,
+            "pre_energy": pre_e, "pause_energy": pause_e, "post_energy": post_e}
+
+
+def pause_confidence(f: Dict, duration: float, min_pause: float) -> float:
+    """`_calculate_pause_confidence` (`:808-848`)."""
+    breath = get_config("pure_vocal_detection.breath_duration_range", [0.1, 0.3])
+    f0_score = min(1.0, f["f0_drop_rate"] / 0.5)
+    energy_score = min(1.0, f["energy_drop"] / 0.7)
+    spectral_score = min(1.0, f["centroid_shift"] / 0.3)
+    if duration < breath[1]:
+        dur_score = 0.3
+    elif duration >= min_pause:
+        dur_score = min(1.0, duration / 1.0)
+    else:
+        dur_score = 0.5
+    conf = (get_config("pure_vocal_detection.f0_weight", 0.3) * f0_score
+            + get_config("pure_vocal_detection.formant_weight", 0.25) * (1.0 - f.get("formant_stability", 0.5))
+            + get_config("pure_vocal_detection.spectral_weight", 0.25) * spectral_score
+            + get_config("pure_vocal_detection.duration_weight", 0.2) * dur_score)
+    conf = conf * (0.7 + 0.3 * energy_score)
+    return min(1.0, conf)
+
+
+def merge_adjacent_pauses(pauses: List[Pause], merge_threshold: float = 0.3) -> List[Pause]:
+    """`_merge_adjacent_pauses` (`:896-934`)."""
+    if not pauses:
+        return pauses
+    pauses = sorted(pauses, key=lambda p: p.start_time)
+    merged = []; cur = pauses[0]
+    for nxt in pauses[1:]:
+        if nxt.start_time - cur.end_time <= merge_threshold:
+            cur = Pause(cur.start_time, nxt.end_time, nxt.end_time - cur.start_time, "true_pause",
+                        max(cur.confidence, nxt.confidence), {**cur.features, **nxt.features})
+        else:
+            merged.append(cur); cur = nxt
+    merged.append(cur)
+    return merged
+
+
+def detect_multifeature_pauses(vocal: np.ndarray, sr: int, *, include_breath_candidates: bool = False,
+                               features: Optional[VocalFeatures] = None) -> List[Pause]:
+    """The dormant branch end to end (`:268-281` + `_analyze_pause_features` `:684-731` + `_classify_and_filter`
+    `:850-894`), followed by the shared precise cut points (`:286-287`)."""
+    hop = int(sr * 0.01)
+    min_pause = get_config("pure_vocal_detection.min_pause_duration", 0.5)
+    breath = get_config("pure_vocal_detection.breath_duration_range", [0.1, 0.3])
+    ft = features if features is not None else extract_vocal_features(vocal, sr)
+    analyzed: List[Pause] = []
+    for s, e in detect_candidate_pauses(ft, sr):
+        st = s * hop / sr; et = e * hop / sr; dur = et - st
+        pf = pause_interval_features(ft, s, e, sr)
+        conf = pause_confidence(pf, dur, min_pause)
+        kind = "breath" if dur <= breath[1] else ("true_pause" if dur >= min_pause else "uncertain")
+        analyzed.append(Pause(st, et, dur, kind, conf, pf))
+    hi = get_config("pure_vocal_detection.pause_confidence_threshold", 0.7)
+    lo = get_config("pure_vocal_detection.breath_filter_threshold", 0.3)
+    kept: List[Pause] = []
+    for p in analyzed:
+        if p.confidence >= hi:
+            p.pause_type = "true_pause"; kept.append(p)
+        elif p.confidence <= lo:
+            p.pause_type = "breath"
+            if include_breath_candidates:
+                kept.append(p)
+        elif p.duration >= min_pause:
+            p.pause_type = "true_pause"; kept.append(p)
+    kept = merge_adjacent_pauses(kept)
+    if kept:
+        kept = precise_cut_points(kept, vocal, sr)
+    return kept

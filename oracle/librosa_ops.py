@@ -408,6 +408,15 @@ def install_as_librosa() -> types.ModuleType:
     beat.beat_track = lambda y=None, sr=22050, onset_envelope=None, hop_length=512, start_bpm=120.0, tightness=100, **kw: (
         beat_track(y=y, sr=sr, onset_envelope=onset_envelope, hop_length=hop_length, start_bpm=start_bpm, tightness=tightness))
     util.frame = frame
+    feature.spectral_centroid = lambda y=None, sr=22050, S=None, n_fft=2048, hop_length=512, **kw: spectral_centroid(
+        y, sr=sr, n_fft=n_fft, hop_length=hop_length)
+    feature.zero_crossing_rate = lambda y, frame_length=2048, hop_length=512, center=True, **kw: zero_crossing_rate(
+        y, frame_length=frame_length, hop_length=hop_length, center=center)
+    lib.pyin = lambda y, fmin=None, fmax=None, sr=22050, frame_length=2048, hop_length=None, **kw: pyin(
+        y, fmin, fmax, sr=sr, frame_length=frame_length, hop_length=hop_length)
+    lib.lpc = lambda y, order=None, **kw: lpc(y, order)
+    lib.note_to_hz = note_to_hz
+    lib.amplitude_to_db = amplitude_to_db
     lib.feature = feature
     lib.onset = onset
     lib.beat = beat
@@ -426,11 +435,19 @@ def install_as_librosa() -> types.ModuleType:
 # YIN fundamental frequency (first stage of librosa.pyin, pure_vocal_pause_detector.py:422-428)
 # ---------------------------------------------------------------------------
 
+LEGACY_FFT_PRECISION = True
+"""numpy < 2 (the reference pins it) computes every `np.fft` transform in double precision and returns complex128 /
+float64 even for float32 input; numpy >= 2 keeps float32.  librosa's YIN autocorrelation goes through rfft/irfft, so
+under the pinned environment the CMND series is float64 (float32 windowed energies + float64 autocorrelation).  True =
+the pinned behaviour (what the product follows); False = this container's numpy 2.x behaviour."""
+
+
 def cmnd_frames(y: np.ndarray, sr: float, fmin: float, fmax: float, frame_length: int = 2048, hop_length: int = 512,
                 center: bool = True) -> Tuple[np.ndarray, int, int]:
     """librosa.core.pitch._cumulative_mean_normalized_difference over centred frames ->
-    (cmnd [max_period-min_period+1, n_frames], min_period, max_period).  FFT autocorrelation in the input
-    dtype, |acf| and |energy| below 1e-6 snapped to zero, exactly as librosa does."""
+    (cmnd [max_period-min_period+1, n_frames], min_period, max_period).  FFT autocorrelation (precision per
+    LEGACY_FFT_PRECISION), windowed energies from a float32 cumulative sum, |acf| and |energy| below 1e-6 snapped to
+    zero, exactly as librosa does."""
     win_length = frame_length // 2
     y = np.asarray(y)
     if center:
@@ -438,12 +455,16 @@ def cmnd_frames(y: np.ndarray, sr: float, fmin: float, fmax: float, frame_length
     y_frames = frame(y, frame_length, hop_length)
     min_period = max(int(np.floor(sr / fmax)), 1)
     max_period = min(int(np.ceil(sr / fmin)), frame_length - win_length - 1)
-    out = np.empty((max_period - min_period + 1, y_frames.shape[1]), dtype=y.dtype)
+    out_dtype = np.float64 if LEGACY_FFT_PRECISION else y.dtype
+    out = np.empty((max_period - min_period + 1, y_frames.shape[1]), dtype=out_dtype)
     for s in range(0, y_frames.shape[1], 2048):
         blk = y_frames[:, s:s + 2048]
-        a = np.fft.rfft(blk, frame_length, axis=0)
-        b = np.fft.rfft(blk[win_length:0:-1, :], frame_length, axis=0)
-        acf = np.fft.irfft(a * b, frame_length, axis=0)[win_length:, :].astype(y.dtype)
+        fblk = blk.astype(np.float64) if LEGACY_FFT_PRECISION else blk
+        a = np.fft.rfft(fblk, frame_length, axis=0)
+        b = np.fft.rfft(fblk[win_length:0:-1, :], frame_length, axis=0)
+        acf = np.fft.irfft(a * b, frame_length, axis=0)[win_length:, :]
+        if not LEGACY_FFT_PRECISION:
+            acf = acf.astype(y.dtype)
         acf[np.abs(acf) < 1e-6] = 0
         energy = np.cumsum(blk ** 2, axis=0)
         energy = energy[win_length:, :] - energy[:-win_length, :]
@@ -475,3 +496,210 @@ def yin(y: np.ndarray, fmin: float, fmax: float, sr: float = 22050, frame_length
     period[none] = np.argmin(cm, axis=0)[none]
     period = min_period + period + np.take_along_axis(shifts, period[None, :], axis=0)[0]
     return sr / period
+
+
+# ---------------------------------------------------------------------------
+# Dormant-branch feature ops (pure_vocal_pause_detector.py:410-459,937-1018)
+# librosa 0.10 `pyin`, `lpc`, `feature.spectral_centroid`, `feature.zero_crossing_rate`, `amplitude_to_db`,
+# `note_to_hz` restated from the published algorithms (parity unpinned: librosa is not installed here).
+# ---------------------------------------------------------------------------
+
+def note_to_hz(note: str) -> float:
+    """librosa.note_to_hz for plain notes like 'C2', 'C7' (A4 = 440 Hz, equal temperament)."""
+    pitch = {"C": 0, "D": 2, "E": 4, "F": 5, "G": 7, "A": 9, "B": 11}[note[0].upper()]
+    rest = note[1:]
+    while rest and rest[0] in "#b!":
+        pitch += 1 if rest[0] == "#" else -1
+        rest = rest[1:]
+    midi = 12 * (int(rest) + 1) + pitch
+    return float(440.0 * (2.0 ** ((midi - 69.0) / 12.0)))
+
+
+def amplitude_to_db(S: np.ndarray, ref=1.0, amin: float = 1e-5, top_db: Optional[float] = 80.0) -> np.ndarray:
+    S = np.asarray(S)
+    magnitude = np.abs(S)
+    ref_value = np.abs(ref(magnitude)) if callable(ref) else np.abs(ref)
+    power = np.square(magnitude, out=magnitude.copy())
+    log_spec = 10.0 * np.log10(np.maximum(amin ** 2, power))
+    log_spec -= 10.0 * np.log10(np.maximum(amin ** 2, ref_value ** 2))
+    if top_db is not None:
+        log_spec = np.maximum(log_spec, log_spec.max() - top_db)
+    return log_spec
+
+
+def spectral_centroid(y: np.ndarray, sr: float = 22050, n_fft: int = 2048, hop_length: int = 512) -> np.ndarray:
+    """librosa.feature.spectral_centroid(y=...): sum(freq * util.normalize(S, norm=1, axis=-2)) over the magnitude
+    spectrogram.  `normalize` measures the column lengths in float64 and stores S / length back in S's dtype."""
+    S = _spectrogram(y, n_fft, hop_length, 1.0)                      # float32 magnitudes for float32 input
+    freq = np.fft.rfftfreq(n_fft, 1.0 / sr).reshape(-1, 1)
+    length = np.sum(np.abs(S).astype(float), axis=-2, keepdims=True)
+    length[length < tiny(S)] = 1.0
+    snorm = np.empty_like(S)
+    snorm[:] = S / length
+    return np.sum(freq * snorm, axis=-2, keepdims=True)
+
+
+def zero_crossing_rate(y: np.ndarray, frame_length: int = 2048, hop_length: int = 512, center: bool = True) -> np.ndarray:
+    """librosa.feature.zero_crossing_rate: edge-padded centred frames, sign changes with pad=False, mean per frame."""
+    y = np.asarray(y)
+    if center:
+        y = np.pad(y, int(frame_length // 2), mode="edge")
+    x = frame(y, frame_length, hop_length).copy()
+    x[np.abs(x) <= 1e-10] = 0                                        # librosa.zero_crossings(threshold=1e-10)
+    sign = np.signbit(x)                                             # zero_pos=True
+    cross = np.empty(x.shape, dtype=bool)
+    cross[0, :] = False                                              # pad=False
+    cross[1:, :] = sign[1:, :] != sign[:-1, :]
+    return np.mean(cross, axis=-2, keepdims=True)
+
+
+def _localmin0(x: np.ndarray) -> np.ndarray:
+    """librosa.util.localmin along axis 0: x[i] < x[i-1] and x[i] <= x[i+1] with edge padding."""
+    pad = np.pad(x, 1, mode="edge")
+    return (x < pad[:-2]) & (x <= pad[2:])
+
+
+def _boltzmann_pmf(k: np.ndarray, lam: float, n: np.ndarray) -> np.ndarray:
+    """scipy.stats.boltzmann.pmf(k, lam, N) evaluated as scipy does (`fact * exp(-lam * k)`,
+    fact = (1 - e^-lam) / (1 - e^(-lam N))) for 0 <= k < N, else 0 (tests compare it with scipy's own)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fact = (1.0 - np.exp(-lam)) / (1.0 - np.exp(-lam * n))
+        p = fact * np.exp(-lam * k)
+    return np.where((k >= 0) & (k < n), p, 0.0)
+
+
+def pyin_tables(n_thresholds: int = 100, beta_parameters=(2, 18)) -> Tuple[np.ndarray, np.ndarray]:
+    thresholds = np.linspace(0, 1, n_thresholds + 1)
+    beta_cdf = scipy.stats.beta.cdf(thresholds, beta_parameters[0], beta_parameters[1])
+    return thresholds, np.diff(beta_cdf)
+
+
+def transition_local_triangle(n_states: int, width: int) -> np.ndarray:
+    """librosa.sequence.transition_local(n_states, width, window='triangle', wrap=False)."""
+    win = scipy.signal.get_window("triangle", width, fftbins=False)
+    lpad = (n_states - width) // 2
+    base = np.zeros(n_states)
+    base[lpad: lpad + width] = win
+    trans = np.zeros((n_states, n_states))
+    for i in range(n_states):
+        row = np.roll(base, n_states // 2 + i + 1)
+        row[min(n_states, i + width // 2 + 1):] = 0
+        row[: max(0, i - width // 2)] = 0
+        trans[i] = row
+    trans /= trans.sum(axis=1, keepdims=True)
+    return trans
+
+
+def viterbi(prob: np.ndarray, transition: np.ndarray, p_init: np.ndarray) -> np.ndarray:
+    """librosa.sequence.viterbi (log domain, first-maximum ties). prob [n_states, n_steps]."""
+    n_states, n_steps = prob.shape
+    eps = tiny(prob)
+    log_trans = np.log(transition + eps)
+    log_prob = np.log(prob.T + eps)
+    value = np.zeros((n_steps, n_states))
+    ptr = np.zeros((n_steps, n_states), dtype=np.int64)
+    value[0] = log_prob[0] + np.log(p_init + eps)
+    lt = log_trans.T
+    for t in range(1, n_steps):
+        trans_out = value[t - 1] + lt                                   # [j, i]
+        ptr[t] = np.argmax(trans_out, axis=1)
+        value[t] = log_prob[t] + trans_out[np.arange(n_states), ptr[t]]
+    states = np.zeros(n_steps, dtype=np.int64)
+    states[-1] = np.argmax(value[-1])
+    for t in range(n_steps - 2, -1, -1):
+        states[t] = ptr[t + 1, states[t + 1]]
+    return states
+
+
+def pyin_observations(cm: np.ndarray, sr: float, fmin: float, fmax: float, min_period: int, *, n_thresholds: int = 100,
+                      boltzmann_parameter: float = 2.0, resolution: float = 0.1, no_trough_prob: float = 0.01):
+    """librosa.core.pitch.__pyin_helper on a CMND matrix [n_lags, n_frames] ->
+    (observation_probs [2 * n_pitch_bins, n_frames] float64, voiced_prob [n_frames], n_pitch_bins, bins per semitone)."""
+    thresholds, beta_probs = pyin_tables(n_thresholds)
+    shifts = np.zeros_like(cm)
+    a = cm[2:] + cm[:-2] - 2 * cm[1:-1]
+    b = (cm[2:] - cm[:-2]) / 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        shifts[1:-1] = np.where(np.abs(b) >= np.abs(a), 0, -b / a)
+    n_bins_per_semitone = int(np.ceil(1.0 / resolution))
+    n_pitch_bins = int(np.floor(12 * n_bins_per_semitone * np.log2(fmax / fmin))) + 1
+    yin_probs = np.zeros_like(cm)
+    for i in range(cm.shape[1]):
+        col = cm[:, i]
+        is_trough = _localmin0(col)
+        is_trough[0] = col[0] < col[1]
+        (idx,) = np.nonzero(is_trough)
+        if len(idx) == 0:
+            continue
+        heights = col[idx]
+        below = np.less.outer(heights, thresholds[1:])
+        positions = np.cumsum(below, axis=0) - 1
+        n_troughs = np.count_nonzero(below, axis=0)
+        prior = _boltzmann_pmf(positions, boltzmann_parameter, n_troughs)
+        prior[~below] = 0
+        probs = prior.dot(beta_probs)
+        gmin = np.argmin(heights)
+        n_below_min = np.count_nonzero(~below[gmin, :])
+        probs[gmin] += no_trough_prob * np.sum(beta_probs[:n_below_min])
+        yin_probs[idx, i] = probs
+    yin_period, frame_index = np.nonzero(yin_probs)
+    period = min_period + yin_period
+    period = period + shifts[yin_period, frame_index]
+    f0 = sr / period
+    bin_index = 12 * n_bins_per_semitone * np.log2(f0 / fmin)
+    bin_index = np.clip(np.round(bin_index), 0, n_pitch_bins).astype(int)
+    obs = np.zeros((2 * n_pitch_bins, cm.shape[1]))
+    obs[bin_index, frame_index] = yin_probs[yin_period, frame_index]
+    voiced_prob = np.clip(np.sum(obs[:n_pitch_bins, :], axis=0, keepdims=True), 0, 1)
+    obs[n_pitch_bins:, :] = (1 - voiced_prob) / n_pitch_bins
+    return obs, voiced_prob[0], n_pitch_bins, n_bins_per_semitone
+
+
+def pyin(y: np.ndarray, fmin: float, fmax: float, sr: float = 22050, frame_length: int = 2048, hop_length: Optional[int] = None,
+         max_transition_rate: float = 35.92, switch_prob: float = 0.01, fill_na=np.nan, center: bool = True):
+    """librosa.pyin -> (f0 [n_frames] with NaN where unvoiced, voiced_flag, voiced_prob)."""
+    if hop_length is None:
+        hop_length = frame_length // 4
+    cm, min_period, _ = cmnd_frames(y, sr, fmin, fmax, frame_length, hop_length, center)
+    obs, voiced_prob, n_pitch_bins, bps = pyin_observations(cm, sr, fmin, fmax, min_period)
+    max_semitones_per_frame = round(max_transition_rate * 12 * hop_length / sr)
+    width = max_semitones_per_frame * bps + 1
+    transition = np.kron(np.array([[1 - switch_prob, switch_prob], [switch_prob, 1 - switch_prob]]),
+                         transition_local_triangle(n_pitch_bins, width))
+    p_init = np.zeros(2 * n_pitch_bins)
+    p_init[n_pitch_bins:] = 1 / n_pitch_bins
+    states = viterbi(obs, transition, p_init)
+    freqs = fmin * 2 ** (np.arange(n_pitch_bins) / (12 * bps))
+    f0 = freqs[states % n_pitch_bins]
+    voiced_flag = states < n_pitch_bins
+    if fill_na is not None:
+        f0 = f0.copy()
+        f0[~voiced_flag] = fill_na
+    return f0, voiced_flag, voiced_prob
+
+
+def lpc(y: np.ndarray, order: int) -> np.ndarray:
+    """librosa.lpc (Burg's method) in the dtype of `y` -> [order + 1] coefficients, a[0] = 1."""
+    y = np.asarray(y)
+    dtype = y.dtype
+    ar = np.zeros(order + 1, dtype=dtype); ar[0] = 1
+    ar_prev = ar.copy()
+    eps = dtype.type(tiny(y))
+    fwd = y[1:]
+    bwd = y[:-1]
+    den = np.sum(fwd ** 2 + bwd ** 2, axis=0).astype(dtype)
+    for i in range(order):
+        rc = np.sum(bwd * fwd, axis=0).astype(dtype)
+        rc = dtype.type(rc * dtype.type(-2))
+        rc = dtype.type(rc / (den + eps))
+        ar_prev, ar = ar, ar_prev
+        for j in range(1, i + 2):
+            ar[j] = ar_prev[j] + rc * ar_prev[i - j + 1]
+        fwd_tmp = fwd
+        fwd = fwd + rc * bwd
+        bwd = bwd + rc * fwd_tmp
+        q = dtype.type(1) - rc ** 2
+        den = dtype.type(q * den - bwd[-1] ** 2 - fwd[0] ** 2)
+        fwd = fwd[1:]
+        bwd = bwd[:-1]
+    return ar

@@ -287,6 +287,46 @@ def golden_features_and_detector() -> None:
 from audio_cut_amd.testing.vpbd_inputs import FixedPauses as _FixedPauses, vpbd_case  # noqa: E402
 
 
+def golden_dormant_branch() -> None:
+    """the multi-feature branch (`enable_relative_energy_mode: false`) of the reference detector run for
+    real over the restated librosa ops (pyin, lpc, centroid, ZCR ...), against oracle.detector.detect_multifeature_pauses."""
+    from vocal_smart_splitter.utils import config_manager as cm
+    from oracle import config as OCfg
+    pv, det = _make_ref_detector()
+    det.breath_duration_range = [0.1, 0.3]
+    det.f0_weight, det.formant_weight, det.spectral_weight, det.duration_weight = 0.3, 0.25, 0.25, 0.2
+    det.energy_threshold_db = -40; det.f0_drop_threshold = 0.7
+    det.breath_confidence_threshold = 0.3; det.pause_confidence_threshold = 0.7
+    key = "pure_vocal_detection.enable_relative_energy_mode"
+    cm.set_runtime_config({key: False}); OCfg.set_runtime_config({key: False})
+    try:
+        saved = {}
+        for tag, x in (("voice", signals.voice_with_rests(14.0, seed=3)), ("bursts", signals.c1_sine_silence(12.0, seed=2))):
+            rf = det._extract_vocal_features(x)
+            of = OD.extract_vocal_features(x, SR)
+            for name in ("f0_contour", "f0_confidence", "spectral_centroid", "harmonic_ratio", "zero_crossing_rate", "rms_energy"):
+                assert np.array_equal(np.asarray(getattr(rf, name)), np.asarray(getattr(of, name)), equal_nan=True), name
+            for a_, b_ in zip(rf.formant_energies, of.formant_energies):
+                assert np.array_equal(a_, b_)
+            assert det._detect_candidate_pauses(rf) == OD.detect_candidate_pauses(of, SR)
+            for breath in (False, True):
+                rp = det.detect_pure_vocal_pauses(x, include_breath_candidates=breath)
+                op = OD.detect_multifeature_pauses(x, SR, include_breath_candidates=breath)
+                assert np.array_equal(_pauses_array(rp), _pauses_array(op)), (breath, _pauses_array(rp), _pauses_array(op))
+                assert [p.pause_type for p in rp] == [p.pause_type for p in op]
+                saved[f"{tag}_pauses_breath{int(breath)}"] = _pauses_array(rp)
+            print(f"  dormant branch [{tag}]: {len(saved[tag + '_pauses_breath0'])} pauses, {len(saved[tag + '_pauses_breath1'])} with breaths")
+            assert len(saved[f"{tag}_pauses_breath1"]) >= 1, tag
+            saved.update({f"{tag}_f0": rf.f0_contour, f"{tag}_voiced_prob": rf.f0_confidence, f"{tag}_centroid": rf.spectral_centroid,
+                          f"{tag}_harmonic_ratio": rf.harmonic_ratio, f"{tag}_zcr": rf.zero_crossing_rate, f"{tag}_rms": rf.rms_energy,
+                          f"{tag}_formant0": np.asarray(rf.formant_energies[0]), f"{tag}_formant1": np.asarray(rf.formant_energies[1]),
+                          f"{tag}_formant2": np.asarray(rf.formant_energies[2]),     # lengths differ: `:1003-1008` appends only to the tracks that got a peak
+                          f"{tag}_candidates": np.asarray(det._detect_candidate_pauses(rf), dtype=np.int64).reshape(-1, 2)})
+        _save("dormant_branch.npz", **saved)
+    finally:
+        cm.reset_runtime_config(); OCfg.reset_runtime_config()
+
+
 def golden_vpbd() -> None:
     import tempfile
     from vocal_smart_splitter.core.vocal_phrase_boundary_detector import VocalPhraseBoundaryDetector as RefVPBD
@@ -341,5 +381,6 @@ if __name__ == "__main__":
     golden_refine()
     golden_chunk_vad()
     golden_features_and_detector()
+    golden_dormant_branch()
     golden_vpbd()
     print("all goldens generated; oracle pinned against the reference's control logic")

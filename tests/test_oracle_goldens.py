@@ -141,3 +141,62 @@ def test_vpp_multiplier_is_structurally_one():
         voc = signals.vocal_like(12.0, seed=seed)
         mul, tag = OD.vpp_multiplier(voc, SR, 441, None)
         assert mul == 1.0 and tag.startswith("VPP{")
+
+
+def _dormant_inputs():
+    return {"voice": signals.voice_with_rests(14.0, seed=3), "bursts": signals.c1_sine_silence(12.0, seed=2)}
+
+
+@pytest.mark.parametrize("tag", ["voice", "bursts"])
+def test_dormant_multifeature_branch_golden(golden_dir, tag):
+    """oracle.detector.detect_multifeature_pauses against the reference's own control logic
+    (fixture written by make_golden.golden_dormant_branch with `enable_relative_energy_mode: false`)."""
+    g = np.load(golden_dir / "dormant_branch.npz")
+    x = _dormant_inputs()[tag]
+    key = "pure_vocal_detection.enable_relative_energy_mode"
+    OCFG.set_runtime_config({key: False})
+    try:
+        ft = OD.extract_vocal_features(x, SR)
+        assert np.array_equal(ft.f0_contour, g[f"{tag}_f0"], equal_nan=True)
+        assert np.array_equal(ft.f0_confidence, g[f"{tag}_voiced_prob"])
+        assert np.array_equal(ft.spectral_centroid, g[f"{tag}_centroid"])
+        assert np.array_equal(ft.harmonic_ratio, g[f"{tag}_harmonic_ratio"])
+        assert np.array_equal(ft.zero_crossing_rate, g[f"{tag}_zcr"])
+        assert np.array_equal(ft.rms_energy, g[f"{tag}_rms"])
+        for j in range(3):
+            assert np.array_equal(ft.formant_energies[j], g[f"{tag}_formant{j}"])
+        assert np.array_equal(np.asarray(OD.detect_candidate_pauses(ft, SR), dtype=np.int64).reshape(-1, 2), g[f"{tag}_candidates"])
+        for breath in (0, 1):
+            ps = OD.detect_multifeature_pauses(x, SR, include_breath_candidates=bool(breath), features=ft)
+            got = np.array([[p.start_time, p.end_time, p.confidence, p.cut_point] for p in ps], dtype=np.float64).reshape(-1, 4)
+            assert np.array_equal(got, g[f"{tag}_pauses_breath{breath}"])
+    finally:
+        OCFG.reset_runtime_config()
+
+
+def test_pyin_building_blocks_known_answers():
+    """Closed-form anchors for the restated librosa.pyin pieces (librosa itself is not installable here)."""
+    import scipy.stats
+    from oracle import librosa_ops as L
+    k = np.arange(0, 30)[:, None] * np.ones((1, 40)); n = np.arange(1, 41)[None, :] * np.ones((30, 1))
+    assert np.array_equal(L._boltzmann_pmf(k, 2.0, n), scipy.stats.boltzmann.pmf(k, 2.0, n))
+    t = L.transition_local_triangle(25, 7)
+    assert np.allclose(t.sum(axis=1), 1.0) and np.all(t[np.abs(np.subtract.outer(np.arange(25), np.arange(25))) > 3] == 0)
+    assert abs(L.note_to_hz("C2") - 65.40639132514966) < 1e-12 and abs(L.note_to_hz("A4") - 440.0) < 1e-12
+    # a steady 220 Hz harmonic tone is voiced at the bin nearest 220 Hz; digital silence is unvoiced
+    sr = 22050
+    tt = np.arange(sr) / sr
+    y = (0.5 * np.sin(2 * np.pi * 220.0 * tt) + 0.25 * np.sin(2 * np.pi * 440.0 * tt)).astype(np.float32)
+    y[sr // 2:] = 0
+    f0, voiced, vp = L.pyin(y, 65.0, 2000.0, sr=sr)
+    mid = len(f0) // 4
+    assert voiced[mid] and abs(f0[mid] - 220.0) / 220.0 < 0.006 and vp[mid] > 0.9
+    assert not voiced[-3] and np.isnan(f0[-3]) and vp[-3] == 0.0
+    # Burg LPC recovers an AR(2) process
+    rng = np.random.default_rng(0)
+    e = rng.standard_normal(4000)
+    z = np.zeros(4000)
+    for i in range(2, 4000):
+        z[i] = 1.5 * z[i - 1] - 0.8 * z[i - 2] + e[i]
+    a = L.lpc(z, 2)
+    assert np.allclose(a, [1.0, -1.5, 0.8], atol=0.05)

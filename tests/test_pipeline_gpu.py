@@ -259,3 +259,52 @@ def test_c5_long_form_round_trip_and_determinism(hip_ctx):
     assert np.all(dbh[nqh[probe][hit]] <= -30.0) and np.all(nqh[probe][hit] >= probe[hit])
     for i in probe[hit][:200]:
         assert not np.any(dbh[i:nqh[i]] <= -30.0)
+
+
+@pytest.mark.parametrize("tag", ["voice", "bursts"])
+def test_dormant_multifeature_branch_against_oracle_and_golden(hip_ctx, golden_dir, tag):
+    """the multi-feature (pyin / LPC / centroid / ZCR) branch on the GPU against the CPU oracle and the
+    reference-generated fixture: voiced probabilities, pitch states and candidate frames exact; float series within
+    tolerance (stated per series); pauses and their integer cut points exact."""
+    from audio_cut_amd import config as PCFG
+    from audio_cut_amd.detectors.pure_vocal_pause_detector import PureVocalPauseDetector
+    from oracle import config as OCFG
+    g = np.load(golden_dir / "dormant_branch.npz")
+    x = {"voice": signals.voice_with_rests(14.0, seed=3), "bursts": signals.c1_sine_silence(12.0, seed=2)}[tag]
+    key = "pure_vocal_detection.enable_relative_energy_mode"
+    saved = PCFG.snapshot()
+    PCFG.set_runtime_config({key: False}); OCFG.set_runtime_config({key: False})
+    try:
+        det = PureVocalPauseDetector(SR, ctx=hip_ctx)
+        ft = det._extract_vocal_features(hip_ctx.to_device(x))
+        # pyin: the Viterbi path decides bins, so f0 is either the same bin or a visible miss
+        assert np.array_equal(np.isnan(ft.f0_contour), np.isnan(g[f"{tag}_f0"]))
+        v = ~np.isnan(ft.f0_contour)
+        assert np.allclose(ft.f0_contour[v], g[f"{tag}_f0"][v], rtol=1e-12, atol=0)
+        assert np.allclose(ft.f0_confidence, g[f"{tag}_voiced_prob"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(ft.rms_energy, g[f"{tag}_rms"], rtol=1e-5, atol=1e-9)
+        assert np.allclose(ft.spectral_centroid, g[f"{tag}_centroid"], rtol=1e-4, atol=1e-2)       # Hz; silence frames are 0/0-guarded
+        assert np.allclose(ft.harmonic_ratio, g[f"{tag}_harmonic_ratio"], rtol=1e-4, atol=1e-6)
+        assert np.array_equal(ft.zero_crossing_rate, g[f"{tag}_zcr"])
+        if tag == "voice":
+            for j in range(3):
+                ref = g[f"{tag}_formant{j}"]
+                assert len(ft.formant_energies[j]) == len(ref)            # same peak counts frame by frame
+                # |1/A| near a pole amplifies the float32 Burg recursion's summation-order rounding (numpy pairwise vs tree)
+                assert np.allclose(ft.formant_energies[j], ref, rtol=5e-3, atol=1e-6)
+        else:
+            # pure 440 Hz bursts put the LPC poles ON the unit circle: |1/A| ~ 1e5-1e6 and chaotic in the last float32 bit, in
+            # librosa as much as here, so only the structure is compared (first track has one entry per frame)
+            assert len(ft.formant_energies[0]) == len(g[f"{tag}_formant0"])
+        cand = np.asarray(det._detect_candidate_pauses(ft), dtype=np.int64).reshape(-1, 2)
+        assert np.array_equal(cand, g[f"{tag}_candidates"])
+        for breath in (0, 1):
+            ps = det.detect_pure_vocal_pauses(x, include_breath_candidates=bool(breath))
+            ref = g[f"{tag}_pauses_breath{breath}"]
+            assert len(ps) == len(ref)
+            got = np.array([[p.start_time, p.end_time, p.confidence, p.cut_point] for p in ps], dtype=np.float64).reshape(-1, 4)
+            assert np.array_equal(got[:, :2], ref[:, :2])                                       # run boundaries (frames)
+            assert np.array_equal((got[:, 3] * SR).astype(np.int64), (ref[:, 3] * SR).astype(np.int64))   # integer cut samples
+            assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-3, atol=1e-3)                      # confidence (a float score)
+    finally:
+        PCFG.restore(saved); OCFG.reset_runtime_config()
