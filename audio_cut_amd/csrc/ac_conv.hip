@@ -12,7 +12,7 @@
 // pre-packed on the host in MFMA fragment order), B = activations (N = an 8 x 32 pixel tile, 4 waves x 64 pixels).
 // K is walked in blocks of 16 input channels; inside a block the 9 taps are paired into 5 k-steps of 32
 // (lane groups 0-1 carry tap 2p, groups 2-3 tap 2p+1; the 10th slot has zero weights).  Per block the
-// (8+2) x (32+2) x 16 input patch is converted to f16 hi/lo once and staged in LDS as [pixel][channel].
+// (8+2) x (32+8) x 16 input patch is converted to f16 hi/lo once and staged in LDS as [pixel][channel].
 // Staging loads are aligned float4 (a 40-column span per patch row); the epilogue (+ bias, optional ReLU) goes through
 // LDS so that every output row segment leaves as one 128-byte line.
 #include "ac_common.h"
@@ -25,16 +25,24 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CV_PH (CV_TH + 2)
 #define CV_PW (CV_TW + 2)
 #define CV_CB 16                 // input channels per LDS stage
-#define CV_PIX_STRIDE 24         // bf16 elements per pixel row in LDS (16 used + 8 pad -> 48-byte stride)
+#define CV_PIX_STRIDE 16         // f16 elements per staged pixel (32 bytes, no padding: see the LDS layout note below)
+#define CV_LW 40                 // staged columns per patch row: the 10 aligned float4 of a row, x0 - 4 .. x0 + 35
 #define CV_COB 48                // output channels per workgroup (3 MFMA row tiles)
 #define CV_MT 3
 
 __device__ inline unsigned short f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
-// staging work items: (row 0..9, aligned column quad 0..9 covering x0-4 .. x0+35, channel quad 0..3)
+// LDS layout of the staged patch: [row 0..9][column 0..39][16 channels] f16, hi and lo separately, 32 bytes per pixel.
+// ds_read_b128 serves a wave in four fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): with 16
+// consecutive pixels per group and the two channel halves 16 bytes apart, a 32-byte pixel stride is conflict-free
+// (the former 48-byte stride was 2-way: SQ_LDS_BANK_CONFLICT was 46 % of the LDS cycles).  ds_write_b64 serves 16
+// contiguous lanes per cycle on a 128-byte bank window, so the staging items are ordered (channel quad, column quad
+// low bits) fastest and odd column quads swap their pixel pairs (`cv_phys`): writes are at most 2-way.
+// staging work items: (row 0..9, column quad 0..9 (+2 idle), channel quad 0..3) -> 480 slots, 400 live
 #define CV_QUADS 10
-#define CV_ITEMS (CV_PH * CV_QUADS * (CV_CB / 4))                          // 400
+#define CV_ITEMS (CV_PH * 3 * 16)                                          // 480
 #define CV_ACT_ITERS ((CV_ITEMS + 255) / 256)                              // 2
+__device__ inline int cv_phys(int c) { return c ^ (((c >> 2) & 1) << 1); } // staged column of logical column c (0..39)
 #define CV_WFRAGS (5 * 2 * CV_MT * 64)                                     // 1920 16-byte weight fragments per stage
 #define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
 #define CV_OUT_STRIDE (CV_TW + 4)                                          // floats per (co, row) line of the output staging
@@ -44,11 +52,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int C_in, int C_out, int H, int W, float w_unscale, int bw) {
     // one LDS arena: [hi patch | lo patch | weight fragments] during the K loop, re-used as the output staging tile
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * CV_PH * CV_PW * CV_PIX_STRIDE * 2 + CV_WFRAGS * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * CV_PH * CV_LW * CV_PIX_STRIDE * 2 + CV_WFRAGS * 16];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
-    unsigned short* s_lo = s_hi + CV_PH * CV_PW * CV_PIX_STRIDE;
-    f16x8* s_w = reinterpret_cast<f16x8*>(s_raw + 2 * CV_PH * CV_PW * CV_PIX_STRIDE * 2);
-    float* s_out = reinterpret_cast<float*>(s_raw);       // [48 co][8 rows][CV_OUT_STRIDE] = 55296 B <= arena (63360 B)
+    unsigned short* s_lo = s_hi + CV_PH * CV_LW * CV_PIX_STRIDE;
+    f16x8* s_w = reinterpret_cast<f16x8*>(s_raw + 2 * CV_PH * CV_LW * CV_PIX_STRIDE * 2);
+    float* s_out = reinterpret_cast<float*>(s_raw);       // [48 co][8 rows][CV_OUT_STRIDE] = 55296 B <= arena (56320 B)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_cob = C_out / CV_COB;
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (blocks L and L+8 share an L2), so XCD
@@ -80,25 +88,24 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     const int ci_off = 8 * (g & 1);
     const f16x8* wbase = wpk + (size_t)cob * n_cb * CV_WFRAGS;
 
-    // per-thread staging coordinates (fixed across stages): one aligned float4 of 4 channels each
+    // per-thread staging coordinates (fixed across stages): one aligned float4 (4 pixels) of 4 channels each
     int a_src[CV_ACT_ITERS];                // float offset inside the plane of the float4, -1 = outside the image (zeros)
-    int a_pix[CV_ACT_ITERS];                // patch pixel index of the float4's first column (may be < row start: clipped)
-    int a_col[CV_ACT_ITERS];                // patch column of the first element (-3 .. 33)
-    int a_c4[CV_ACT_ITERS];
+    int a_off[CV_ACT_ITERS];                // LDS element offset of the quad's first pixel (row * CV_LW + 4 * qd) * 16 + c4 * 4
+    int a_c4[CV_ACT_ITERS];                 // channel quad, -1 = idle slot
+    int a_flip[CV_ACT_ITERS];               // odd column quads store their pixel pairs swapped (cv_phys)
 #pragma unroll
     for (int i = 0; i < CV_ACT_ITERS; ++i) {
         const int e = tid + 256 * i;
-        if (e < CV_ITEMS) {
-            const int c4 = e / (CV_PH * CV_QUADS);
-            const int r = e - c4 * (CV_PH * CV_QUADS);
-            const int py = r / CV_QUADS, qd = r - py * CV_QUADS;
+        const int c4 = (e >> 2) & 3, ql = e & 3, rest = e >> 4;
+        const int py = rest / 3, qd = (rest - py * 3) * 4 + ql;
+        if (e < CV_ITEMS && qd < CV_QUADS) {
             const int gy = y0 + py - 1, gx = x0 - 4 + 4 * qd;          // aligned: x0 % 32 == 0
             a_c4[i] = c4;
-            a_col[i] = 4 * qd - 3;                                     // patch column = gx - (x0 - 1)
-            a_pix[i] = py * CV_PW;
+            a_flip[i] = (qd & 1) << 1;
+            a_off[i] = (py * CV_LW + 4 * qd) * CV_PIX_STRIDE + c4 * 4;
             a_src[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
         } else {
-            a_c4[i] = -1; a_col[i] = 0; a_pix[i] = 0; a_src[i] = -1;
+            a_c4[i] = -1; a_flip[i] = 0; a_off[i] = 0; a_src[i] = -1;
         }
     }
     float4 pre_x[CV_ACT_ITERS][4];
@@ -136,8 +143,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
             const float* v4[4] = {&pre_x[i][0].x, &pre_x[i][1].x, &pre_x[i][2].x, &pre_x[i][3].x};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                              // 4 pixels of the float4
-                const int col = a_col[i] + k;
-                if (col < 0 || col >= CV_PW) continue;                 // the 6 alignment columns outside the patch
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                     h4[q] = f16_bits(hv);
                     l4[q] = f16_bits((_Float16)(v - (float)hv));
                 }
-                const int off = (a_pix[i] + col) * CV_PIX_STRIDE + a_c4[i] * 4;
+                const int off = a_off[i] + (k ^ a_flip[i]) * CV_PIX_STRIDE;
                 *reinterpret_cast<uint2*>(&s_hi[off]) = make_uint2((unsigned)h4[0] | ((unsigned)h4[1] << 16), (unsigned)h4[2] | ((unsigned)h4[3] << 16));
                 *reinterpret_cast<uint2*>(&s_lo[off]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
             }
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
-                const int off = ((ty + dy) * CV_PW + (tx + dx)) * CV_PIX_STRIDE + ci_off;
+                const int off = ((ty + dy) * CV_LW + cv_phys(tx + dx + 3)) * CV_PIX_STRIDE + ci_off;   // patch column c is staged column c + 3
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(&s_hi[off]);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(&s_lo[off]);
 #pragma unroll

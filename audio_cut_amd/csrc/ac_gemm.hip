@@ -7,7 +7,7 @@
 //
 // Workgroup: 256 threads = 2 x 2 waves, tile 128 rows x (32 * NT) columns, wave tile 64 x (16 * NT) (NT = 6 or 3).
 // K is walked in stages of 32: the x tile is loaded as full 128-byte row segments (float4 per lane), split to f16
-// hi/lo once and staged in LDS as [row][k] with an 80-byte row stride (conflict-free ds_read_b128 A fragments); the
+// hi/lo once and staged in LDS as [row][k] with an 96-byte row stride (conflict-free ds_read_b128 A fragments); the
 // weights arrive pre-split and pre-packed in B-fragment order (conv_pack.pack_linear) and are copied through.  The
 // next stage's global loads are issued before the current stage's MFMAs.  Epilogue: accumulators -> per-wave LDS
 // strip -> affine + ReLU (+ residual) -> 384-byte (192-byte for NT = 3) contiguous row stores.
@@ -18,7 +18,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define GM_BM 128
 #define GM_BK 32
-#define GM_ASTRIDE 40            // f16 elements per staged x row (32 used + 8 pad -> 80 bytes)
+#define GM_ASTRIDE 48            // f16 per staged x row: 32 used + 16 pad -> 96 bytes (conflict-free for ds_read_b128's four 16-lane groups; 80 was 2-way)
 #define GM_MT 4                  // 16-row tiles per wave
 #define GM_A_ITERS ((GM_BM * (GM_BK / 4)) / 256)     // float4 loads per thread per stage (4)
 

@@ -17,7 +17,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define RS_BM 128
 #define RS_BN 96
 #define RS_BK 32
-#define RS_ASTRIDE 40            // f16 per staged pixel row (32 used + 8 pad -> 80 bytes, conflict-free ds_read_b128)
+#define RS_ASTRIDE 48            // f16 per staged pixel row: 32 used + 16 pad -> 96 bytes (conflict-free for ds_read_b128's four 16-lane groups)
 #define RS_MT 4
 #define RS_NT 3
 #define RS_BFRAGS (2 * (RS_BN / 16) * 64)          // 768 16-byte weight fragments per stage
