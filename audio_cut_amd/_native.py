@@ -87,6 +87,9 @@ SIGNATURES = {
     "ac_lpc_formants": (C.c_int, [_P, _P, _I64, _I, _I, _I, C.c_float, _P, _P, _I64, _P]),
     "ac_zero_crossing_rate": (C.c_int, [_P, _P, _I64, _I, _I, _P, _I64, _P]),
     "ac_stft2048_spectral": (C.c_int, [_P, _P, _I64, _I, C.c_double, _P, _P, _I64, _P]),
+    "ac_segment_frame_rms": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
+    "ac_segment_sumsq_peak": (C.c_int, [_P, _P, _I64, _P, _P, _I, _P, _P, _P]),
+    "ac_local_valley": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -221,6 +224,42 @@ class Context:
         _check(self.lib.ac_yin_f0(self._h, _ptr(x), n, frame_length, hop, min_period, max_period, float(threshold),
                                   _ptr(period), _ptr(cmnd), nf, _stream()))
         return float(sr) / period.cpu().numpy(), cmnd
+
+    # -- post-path boundary policy ----------------------------------------------
+    def segment_frame_rms(self, x: torch.Tensor, seg_start: np.ndarray, seg_end: np.ndarray, frame: int, hop: int):
+        """librosa.feature.rms(y=x[a:b], frame, hop)[0] for every segment in one launch -> list of host float32 arrays."""
+        self._chk_f32(x)
+        a = np.asarray(seg_start, dtype=np.int64); b = np.asarray(seg_end, dtype=np.int64)
+        counts = 1 + (b - a) // hop
+        off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+        nf = int(off[-1])
+        out = torch.empty(nf, dtype=torch.float32, device=self.device)
+        da, db_, do = self.to_device(a), self.to_device(b), self.to_device(off)
+        _check(self.lib.ac_segment_frame_rms(self._h, _ptr(x), x.numel(), _ptr(da), _ptr(db_), _ptr(do), len(a), frame, hop, _ptr(out), nf,
+                                             _stream()))
+        host = out.cpu().numpy()
+        return [host[off[i]: off[i + 1]] for i in range(len(a))]
+
+    def segment_sumsq_peak(self, x: torch.Tensor, seg_start: np.ndarray, seg_end: np.ndarray):
+        """(sum of squares float64, peak |x| float32) per segment, host arrays."""
+        self._chk_f32(x)
+        a = self.to_device(np.asarray(seg_start, dtype=np.int64)); b = self.to_device(np.asarray(seg_end, dtype=np.int64))
+        k = a.numel()
+        ss = torch.empty(k, dtype=torch.float64, device=self.device)
+        pk = torch.empty(k, dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_segment_sumsq_peak(self._h, _ptr(x), x.numel(), _ptr(a), _ptr(b), k, _ptr(ss), _ptr(pk), _stream()))
+        return ss.cpu().numpy(), pk.cpu().numpy()
+
+    def local_valley(self, x: torch.Tensor, centers: np.ndarray, radius: int, win: int):
+        """(orig_db, min_db, min_idx) per boundary, host arrays (see ac_local_valley)."""
+        self._chk_f32(x)
+        c = self.to_device(np.asarray(centers, dtype=np.int64))
+        k = c.numel()
+        od = torch.empty(k, dtype=torch.float64, device=self.device)
+        md = torch.empty(k, dtype=torch.float64, device=self.device)
+        mi = torch.empty(k, dtype=torch.int64, device=self.device)
+        _check(self.lib.ac_local_valley(self._h, _ptr(x), x.numel(), _ptr(c), k, int(radius), int(win), _ptr(od), _ptr(md), _ptr(mi), _stream()))
+        return od.cpu().numpy(), md.cpu().numpy(), mi.cpu().numpy()
 
     # -- multi-feature detector branch (SURVEY.md 8 a19) ---------------------------------------------
     _PYIN_TABLES = None

@@ -143,6 +143,10 @@ class SeamlessSplitter:
                     aug.add(s)
             bounds = sorted(aug)
         t_fin = time.perf_counter() - t2
+        t3 = time.perf_counter()
+        policy = self._apply_boundary_policy(bounds, vocal_track, len(original_audio), cache, vocal_dev=state.get("vocal"))
+        result.update(policy)
+        result["timings_policy_s"] = time.perf_counter() - t3
         result.update({"sample_boundaries": bounds, "refine_boundaries": list(refine.sample_boundaries),
                        "cut_candidates": cut_candidates,
                        "guard_adjustments": list(refine.adjustments or []),
@@ -150,6 +154,254 @@ class SeamlessSplitter:
         return result
 
     # ------------------------------------------------------------------------------------------
+    # ---- post-path boundary policy (reference `seamless_splitter.py:521-669`) -----------
+    def _vocal_on_device(self, vocal_audio: np.ndarray, vocal_dev=None):
+        return vocal_dev if vocal_dev is not None else self._context().to_device(np.ascontiguousarray(vocal_audio, dtype=np.float32))
+
+    def _classify_segments_vocal_presence(self, vocal_audio: np.ndarray, cut_points: Sequence[int], marker_segments=None,
+                                          pure_music_segments=None, instrumental_audio=None, original_audio=None, *,
+                                          vocal_dev=None) -> List[bool]:
+        """`:2276-2403`: a segment is `human` when at least `segment_vocal_activity_ratio` of its 50 ms / 20 ms RMS frames
+        exceed `segment_vocal_threshold_db`.  All segments' frames come from ONE `ac_segment_frame_rms` launch."""
+        n_seg = max(len(cut_points) - 1, 0)
+        self._last_segment_classification_debug = []
+        if n_seg == 0:
+            return []
+        sr = self.sample_rate
+        if sr <= 0 or vocal_audio is None or getattr(vocal_audio, "size", 0) == 0:
+            self._last_segment_classification_debug = [{"index": i, "reason": "fallback_invalid_input", "decision": True} for i in range(n_seg)]
+            return [True] * n_seg
+        ratio_thr = float(get_config("quality_control.segment_vocal_activity_ratio", 0.10))
+        thr_db = float(get_config("quality_control.segment_vocal_threshold_db", -50.0))
+        hop = max(1, int(0.02 * sr))
+        frame_length = max(hop * 2, int(0.05 * sr))
+        n = len(vocal_audio)
+        a = np.clip(np.asarray(cut_points[:-1], dtype=np.int64), 0, n)
+        b = np.maximum(a, np.clip(np.asarray(cut_points[1:], dtype=np.int64), 0, n))
+        hip = self._context()
+        dev = self._vocal_on_device(vocal_audio, vocal_dev)
+        long_ix = np.flatnonzero((b - a) >= frame_length)
+        frames = dict(zip(long_ix.tolist(), hip.segment_frame_rms(dev, a[long_ix], b[long_ix], frame_length, hop))) if long_ix.size else {}
+        short_ix = np.flatnonzero(((b - a) > 0))
+        sumsq = dict(zip(short_ix.tolist(), hip.segment_sumsq_peak(dev, a[short_ix], b[short_ix])[0])) if short_ix.size else {}
+        flags: List[bool] = []
+        debug: List[Dict] = []
+        for i in range(n_seg):
+            t0, t1 = int(a[i]) / sr, int(b[i]) / sr
+            dur = max(t1 - t0, 1e-6)
+            size = int(b[i] - a[i])
+            ratio = seconds = 0.0
+            rms_db = None
+            if i in sumsq:          # np.sqrt(np.mean(np.square(seg)) + 1e-12) of the float32 segment
+                rms_db = 20.0 * np.log10(float(np.sqrt(np.float32(sumsq[i] / size) + np.float32(1e-12))))
+            if i in frames:
+                active = (20.0 * np.log10(frames[i] + 1e-12)) > thr_db
+                if active.size > 0:
+                    ratio = float(np.mean(active))
+                    seconds = float(min(dur, float(active.sum()) * (hop / sr)))
+            elif size > 0 and rms_db > thr_db:
+                ratio, seconds = 1.0, dur
+            decision = ratio >= ratio_thr
+            why = "vocal_activity_ratio_gte_threshold" if decision else "vocal_activity_ratio_lt_threshold"
+            debug.append({"index": i, "start_s": t0, "end_s": t1, "duration_s": dur, "vocal_activity_ratio": ratio,
+                          "vocal_activity_seconds": seconds, "activity_ratio_threshold": ratio_thr, "activity_threshold_db": thr_db,
+                          "rms_db": rms_db, "decision": decision, "decision_reason": why, "reason": why,
+                          "decision_threshold_db": thr_db, "threshold_source": "vocal_activity_ratio"})
+            flags.append(bool(decision))
+        self._last_segment_classification_debug = debug
+        return flags
+
+    def _refine_boundaries_local_valley(self, sample_boundaries: List[int], vocal_audio: np.ndarray, cfg: Dict, *, min_gap_s: float,
+                                        protected_intervals_s=None, vocal_dev=None) -> List[int]:
+        """`:2613-2680`: every interior boundary may move to the quietest 5 ms of its +-radius neighbourhood when that is at
+        least `min_drop_db` quieter; all neighbourhoods are searched in ONE `ac_local_valley` launch on the boundaries as
+        they stand, then the moves are accepted left to right (a move only tightens its neighbours' gap checks, which use
+        the already-updated left boundary exactly as the reference's in-place loop does)."""
+        if vocal_audio is None or vocal_audio.size == 0 or len(sample_boundaries) <= 2:
+            return sample_boundaries
+        sr = float(self.sample_rate)
+        radius = max(1, int(float(cfg.get("search_radius_ms", 200)) / 1000.0 * sr))
+        win = max(1, int(float(cfg.get("window_ms", 20)) / 1000.0 * sr))
+        drop_db = float(cfg.get("min_drop_db", 3.0))
+        micro = float(get_config("segment_layout.micro_merge_s", 0.0) or 0.0)
+        piece = float(get_config("quality_control.segment_min_mix_piece", 0.0) or 0.0)
+        min_seg = max(1, int(max(float(min_gap_s), micro, piece) * sr))
+        protected = sorted((float(x), float(y)) for x, y in (protected_intervals_s or []) if float(y) > float(x))
+        refined = list(sample_boundaries)
+        centers = np.asarray(refined[1:-1], dtype=np.int64)
+        dev = self._vocal_on_device(vocal_audio, vocal_dev)
+        orig_db, min_db, min_idx = self._context().local_valley(dev, centers, radius, win)
+        for k, idx in enumerate(range(1, len(refined) - 1)):
+            if min_idx[k] < 0 or (orig_db[k] - min_db[k]) < drop_db:
+                continue
+            center = refined[idx]
+            cand = max(0, center - radius) + int(min_idx[k]) + win // 2
+            if any(x < cand / sr < y for x, y in protected):
+                continue
+            if cand <= refined[idx - 1] + min_seg or cand >= refined[idx + 1] - min_seg:
+                continue
+            refined[idx] = cand
+        return refined
+
+    def _merge_short_weak_human_tails_into_following_music(self, cut_points: List[int], segment_vocal_flags: List[bool],
+                                                           debug_entries: List[Dict], vocal_audio: np.ndarray, *,
+                                                           min_duration_s: float, layout_applied: bool, vocal_dev=None):
+        """`:2145-2275`: a human segment shorter than `soft_min_s` whose RMS and peak are under 12 % / 18 % of the median
+        long human segment, followed by music, becomes part of that music.  Segment energies come from one
+        `ac_segment_sumsq_peak` launch; a merged pair's statistics are the sums / max of its parts."""
+        debug = [dict(e) for e in (debug_entries or [])]
+        if (not layout_applied or min_duration_s <= 0.0 or len(cut_points) < 3 or len(segment_vocal_flags) != len(cut_points) - 1
+                or vocal_audio is None or getattr(vocal_audio, "size", 0) == 0 or self.sample_rate <= 0):
+            return list(cut_points), list(segment_vocal_flags), debug
+        sr = float(self.sample_rate)
+        n = len(vocal_audio)
+        pts = [int(p) for p in cut_points]
+        flags = [bool(f) for f in segment_vocal_flags]
+        while len(debug) < len(flags):
+            debug.append({})
+        a = np.clip(np.asarray(pts[:-1], dtype=np.int64), 0, n)
+        b = np.maximum(a, np.clip(np.asarray(pts[1:], dtype=np.int64), 0, n))
+        live = np.flatnonzero(b > a)
+        ss = np.zeros(len(a)); pk = np.zeros(len(a))
+        if live.size:
+            s_live, p_live = self._context().segment_sumsq_peak(self._vocal_on_device(vocal_audio, vocal_dev), a[live], b[live])
+            ss[live] = s_live; pk[live] = p_live
+        size = (b - a).astype(np.float64)
+        seg = [{"ss": float(ss[i]), "pk": float(pk[i]), "n": float(size[i])} for i in range(len(a))]
+
+        def stat(i):
+            cnt = seg[i]["n"]
+            rms = float(np.sqrt(seg[i]["ss"] / cnt + 1e-12)) if cnt > 0 else 0.0
+            return max(0.0, (pts[i + 1] - pts[i]) / sr), rms, (seg[i]["pk"] if cnt > 0 else 0.0)
+
+        st = [stat(i) for i in range(len(flags))]
+        ref_r = [r for (d, r, p), f in zip(st, flags) if f and d >= min_duration_s and r > 0.0]
+        ref_p = [p for (d, r, p), f in zip(st, flags) if f and d >= min_duration_s and p > 0.0]
+        if not ref_r or not ref_p:
+            return pts, flags, debug[:len(flags)]
+        rr = float(np.median(np.asarray(ref_r, dtype=np.float64)))
+        rp = float(np.median(np.asarray(ref_p, dtype=np.float64)))
+        w_r = float(get_config("quality_control.short_human_tail_rms_ratio", 0.12) or 0.12)
+        w_p = float(get_config("quality_control.short_human_tail_peak_ratio", 0.18) or 0.18)
+        why = "merged_short_weak_human_tail_into_following_music"
+        i = 0
+        while i < len(flags) - 1:
+            d, r, p = stat(i)
+            if not (flags[i] and not flags[i + 1] and d < min_duration_s and r <= rr * w_r and p <= rp * w_p):
+                i += 1
+                continue
+            t0, t1 = pts[i] / sr, pts[i + 2] / sr
+            pts.pop(i + 1)
+            seg[i:i + 2] = [{"ss": seg[i]["ss"] + seg[i + 1]["ss"], "pk": max(seg[i]["pk"], seg[i + 1]["pk"]), "n": seg[i]["n"] + seg[i + 1]["n"]}]
+            left, right = debug[i], debug[i + 1]
+            merged = dict(right or left or {})
+            span = max(t1 - t0, 1e-6)
+            voiced = min(span, float((left or {}).get("vocal_activity_seconds", 0.0) or 0.0) + float((right or {}).get("vocal_activity_seconds", 0.0) or 0.0))
+            origin = []
+            for e in (left, right):
+                if e:
+                    origin.extend(e.get("merged_from_segments", [e.get("index")]))
+            merged.update({"index": i, "start_s": t0, "end_s": t1, "duration_s": span, "vocal_activity_seconds": voiced,
+                           "vocal_activity_ratio": voiced / span, "decision": False, "decision_reason": why, "reason": why,
+                           "merged_from_segments": sorted({int(x) for x in origin if x is not None})})
+            flags[i:i + 2] = [False]
+            debug[i:i + 2] = [merged]
+        for k, e in enumerate(debug[:len(flags)]):
+            e["index"] = k
+        return pts, flags, debug[:len(flags)]
+
+    def _split_at_sample_level(self, audio: np.ndarray, final_cut_points: List[int], *, segment_flags: Optional[List[bool]] = None,
+                               debug_entries: Optional[List[Dict]] = None):
+        """`:2006-2144`: slices between consecutive cut points; a slice shorter than 10 ms is glued to the next one (a
+        trailing one to the previous).  Slices are views of `audio` unless a merge forces a copy."""
+        keep = max(1, int(0.01 * self.sample_rate))
+        n = len(audio)
+        spans: List[List[int]] = []
+        flags: Optional[List[bool]] = [] if segment_flags is not None else None
+        pending: Optional[List[int]] = None
+        pending_flag: Optional[bool] = None
+        for i in range(len(final_cut_points) - 1):
+            lo = max(0, min(int(final_cut_points[i]), n)); hi = max(lo, min(int(final_cut_points[i + 1]), n))
+            span = [lo, hi] if hi > lo else None
+            flag = bool(segment_flags[i]) if (segment_flags is not None and i < len(segment_flags)) else True
+            if pending is not None:
+                span = [pending[0], span[1]] if span is not None else list(pending)
+                flag = bool(pending_flag) or flag
+                pending, pending_flag = None, None
+            if int(final_cut_points[i + 1]) - int(final_cut_points[i]) >= keep and span is not None:
+                spans.append(span)
+                if flags is not None:
+                    flags.append(flag)
+            elif span is not None:
+                pending, pending_flag = span, flag
+        if pending is not None:
+            if spans:
+                spans[-1][1] = pending[1]
+                if flags is not None:
+                    flags[-1] = bool(flags[-1]) or bool(pending_flag)
+            else:
+                spans.append(pending)
+                if flags is not None:
+                    flags.append(bool(pending_flag))
+        self._last_segment_spans = [tuple(sp) for sp in spans]
+        return [audio[lo:hi] for lo, hi in spans], flags, None
+
+    def _apply_boundary_policy(self, bounds: List[int], vocal_track: np.ndarray, n_samples: int,
+                               cache: Optional[TrackFeatureCache], *, vocal_dev=None) -> Dict:
+        """`:521-669` for the modes without lyrics alignment: classify -> layout refiner -> classify -> local valley ->
+        classify -> weak-tail merge -> sample-level split.  Returns the manifest-facing fields."""
+        from ..cutting.segment_layout_refiner import Segment as LayoutSegment, derive_layout_config, refine_layout
+        sr = self.sample_rate
+        cuts = sorted(set(int(c) for c in bounds))
+        flags = self._classify_segments_vocal_presence(vocal_track, cuts, vocal_dev=vocal_dev)
+        raw = dict(get_config("segment_layout", {}) or {})
+        micro = get_config("quality_control.segment_min_mix_piece", None)
+        if micro is not None:
+            raw.setdefault("micro_merge_s", float(micro)); raw.setdefault("enable", bool(float(micro) > 0.0))
+        smax = get_config("quality_control.segment_max_duration", None)
+        if smax is not None:
+            raw.setdefault("soft_max_s", float(smax))
+        raw.setdefault("min_gap_s", float(get_config("quality_control.min_split_gap", 1.0)))
+        raw.setdefault("beat_snap_ms", float(get_config("segment_layout.beat_snap_ms", 0.0) or 0.0))
+        lcfg = derive_layout_config(raw, cache, sample_rate=sr)
+        applied = False
+        if lcfg.enable and len(cuts) >= 2:
+            edges = [c / float(sr) for c in cuts]
+            res = refine_layout([LayoutSegment(edges[i], edges[i + 1], "human" if flags[i] else "music") for i in range(len(edges) - 1)],
+                                self._last_guard_adjustments_raw, config=lcfg, sample_rate=sr,
+                                suppressed_cut_points=self._last_suppressed_cut_points, features=cache)
+            if res.segments:
+                times = [res.segments[0].start] + [sg.end for sg in res.segments]
+                upd = [max(0, min(int(round(t * sr)), n_samples)) for t in times]
+                if upd:
+                    upd[0] = 0; upd[-1] = n_samples
+                upd = sorted(set(upd))
+                if upd != cuts:
+                    applied = True
+                cuts = upd if upd else cuts
+                self._last_guard_adjustments_raw = list(res.adjustments)
+                self._last_suppressed_cut_points = list(res.suppressed_points or [])
+                flags = self._classify_segments_vocal_presence(vocal_track, cuts, vocal_dev=vocal_dev)
+        local = get_config("quality_control.local_boundary_refine", {}) or {}
+        if local.get("enable") and len(cuts) >= 2:
+            ref = self._refine_boundaries_local_valley(cuts, vocal_track, local, min_gap_s=float(get_config("quality_control.min_split_gap", 1.0)),
+                                                       vocal_dev=vocal_dev)
+            if list(ref) != cuts:
+                cuts = list(ref); applied = True
+                flags = self._classify_segments_vocal_presence(vocal_track, cuts, vocal_dev=vocal_dev)
+        c2, f2, dbg = self._merge_short_weak_human_tails_into_following_music(
+            cuts, flags, list(getattr(self, "_last_segment_classification_debug", [])), vocal_track,
+            min_duration_s=float(getattr(lcfg, "soft_min_s", 0.0) or 0.0), layout_applied=applied, vocal_dev=vocal_dev)
+        if list(c2) != cuts:
+            cuts, flags, applied = list(c2), list(f2), True
+            self._last_segment_classification_debug = dbg
+        _, merged_flags, _ = self._split_at_sample_level(np.empty(n_samples, dtype=np.int8), cuts, segment_flags=flags)
+        spans = list(self._last_segment_spans)
+        return {"cuts_samples": list(cuts), "cuts_sec": [c / float(sr) for c in cuts], "segment_vocal_flags": list(merged_flags or []),
+                "segment_spans": spans, "segment_durations": [(hi - lo) / float(sr) for lo, hi in spans],
+                "segment_layout_applied": bool(applied),
+                "suppressed_cut_points_sec": [float(c.t) for c in self._last_suppressed_cut_points]}
+
     def _rms2048_db(self, wave: np.ndarray, dev=None) -> np.ndarray:
         hip = self._context()
         x = dev if dev is not None else hip.to_device(np.ascontiguousarray(wave, dtype=np.float32))

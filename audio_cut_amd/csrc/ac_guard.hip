@@ -466,3 +466,136 @@ extern "C" int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
+
+// =================================================================================================
+// Post-path boundary policy.
+// (1) framed RMS of every segment of a cut list in ONE launch (`_classify_segments_vocal_presence`,
+//     seamless_splitter.py:2335-2342: librosa.feature.rms(y=segment, frame 2205, hop 882), i.e. centred frames that
+//     see zeros outside their own segment).  One wave per frame; the segment of a frame is found by binary search in
+//     the per-segment frame offsets.
+// (2) local-valley search around each boundary (`_refine_boundaries_local_valley`, :2646-2661): float64 moving mean of
+//     x^2 over `win` samples ('valid'), sqrt(. + 1e-12), 20 log10(. + 1e-12); the value at the boundary and the first
+//     minimum of the +-radius window.  One workgroup per boundary, 1024 outputs per LDS tile.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_segment_frame_rms(const float* __restrict__ x, const int64_t* __restrict__ seg_start,
+                                                           const int64_t* __restrict__ seg_end, const int64_t* __restrict__ frame_off,
+                                                           int n_seg, int frame, int hop, float* __restrict__ out, int64_t n_frames) {
+    const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= n_frames) return;
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = n_seg - 1;                      // last segment with frame_off[s] <= f
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (frame_off[mid] <= f) lo = mid; else hi = mid - 1; }
+    const int64_t a = seg_start[lo], b = seg_end[lo];
+    const int64_t c0 = a + (f - frame_off[lo]) * (int64_t)hop - frame / 2;
+    double acc = 0.0;
+    for (int i = lane; i < frame; i += 64) {
+        const int64_t g = c0 + i;
+        if (g >= a && g < b) { const double v = (double)x[g]; acc += v * v; }
+    }
+    acc = wave_sum_f64(acc);
+    if (lane == 0) out[f] = (float)sqrt(acc / (double)frame);
+}
+
+extern "C" int ac_segment_frame_rms(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end,
+                                     const int64_t* frame_off, int n_seg, int frame, int hop, float* out, int64_t n_frames,
+                                     void* stream) {
+    AC_REQUIRE(ctx && x && seg_start && seg_end && frame_off && out, "null pointer");
+    AC_REQUIRE(n > 0 && n_seg > 0 && frame > 0 && hop > 0 && n_frames > 0 && n_frames < (1LL << 33), "sizes must be positive");
+    hipLaunchKernelGGL(k_segment_frame_rms, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, seg_start,
+                       seg_end, frame_off, n_seg, frame, hop, out, n_frames);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+#define LV_TILE 1024
+#define NQ_INF_I 0x7fffffffffffffffLL
+#define LV_MAX_WIN 2048
+
+__global__ __launch_bounds__(256) void k_local_valley(const float* __restrict__ x, int64_t n, const int64_t* __restrict__ centers,
+                                                      int radius, int win, double* __restrict__ orig_db, double* __restrict__ min_db,
+                                                      int64_t* __restrict__ min_idx) {
+    __shared__ double s_sq[LV_TILE + LV_MAX_WIN];
+    __shared__ double s_bv[4];
+    __shared__ long long s_bi[4];
+    const int k = blockIdx.x;
+    const int64_t c = centers[k];
+    const int64_t a = c - radius < 0 ? 0 : c - radius;
+    const int64_t b = c + radius > n ? n : c + radius;
+    const int64_t len = b - a;
+    if (len <= win) {                                // `if segment.size <= win: continue`
+        if (threadIdx.x == 0) { orig_db[k] = 0.0; min_db[k] = 0.0; min_idx[k] = -1; }
+        return;
+    }
+    const int64_t m = len - win + 1;                 // 'valid' outputs
+    int64_t o = c - a - win / 2;
+    o = o < 0 ? 0 : (o > m - 1 ? m - 1 : o);
+    const double inv = 1.0 / (double)win;
+    double best = INFINITY; long long besti = NQ_INF_I;
+    for (int64_t t0 = 0; t0 < m; t0 += LV_TILE) {
+        const int cnt = (int)((m - t0) < LV_TILE ? (m - t0) : LV_TILE);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt + win - 1; i += 256) { const double v = (double)x[a + t0 + i]; s_sq[i] = v * v; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            double acc = 0.0;
+            for (int j = 0; j < win; ++j) acc += s_sq[i + j] * inv;      // np.convolve(sq, ones / win): products, then the sum
+            const double rms = sqrt(acc + 1e-12);
+            const double db = 20.0 * log10(rms + 1e-12);
+            const long long gi = (long long)(t0 + i);
+            if (gi == o) orig_db[k] = db;
+            if (db < best) { best = db; besti = gi; }                    // ascending i per thread: first minimum kept
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, AC_WAVE); const long long oi = __shfl_down(besti, off, AC_WAVE);
+        if (ov < best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_bv[threadIdx.x >> 6] = best; s_bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_bv[w] < best || (s_bv[w] == best && s_bi[w] < besti)) { best = s_bv[w]; besti = s_bi[w]; }
+        min_db[k] = best; min_idx[k] = besti;
+    }
+}
+
+extern "C" int ac_local_valley(ac_ctx* ctx, const float* x, int64_t n, const int64_t* centers, int k, int radius, int win,
+                                double* orig_db, double* min_db, int64_t* min_idx, void* stream) {
+    AC_REQUIRE(ctx && x && centers && orig_db && min_db && min_idx, "null pointer");
+    AC_REQUIRE(n > 0 && k > 0 && radius > 0 && win > 0 && win <= LV_MAX_WIN, "0 < win <= 2048, radius > 0");
+    hipLaunchKernelGGL(k_local_valley, dim3((unsigned)k), dim3(256), 0, (hipStream_t)stream, x, n, centers, radius, win, orig_db,
+                       min_db, min_idx);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+// (3) per-segment sum of squares (float64) and peak |x| for the weak-tail rule (`_merge_short_weak_human_tails_...`,
+//     seamless_splitter.py:2179-2196) and the short-segment branch of the classifier (:2349-2358).  One workgroup per
+//     segment, fixed-order tree reduction (deterministic).
+__global__ __launch_bounds__(256) void k_segment_sumsq_peak(const float* __restrict__ x, const int64_t* __restrict__ seg_start,
+                                                            const int64_t* __restrict__ seg_end, double* __restrict__ sumsq,
+                                                            float* __restrict__ peak) {
+    __shared__ double s_s[4];
+    __shared__ float s_p[4];
+    const int s = blockIdx.x;
+    const int64_t a = seg_start[s], b = seg_end[s];
+    double acc = 0.0; float pk = 0.f;
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) { const float v = x[i]; acc += (double)v * (double)v; pk = fmaxf(pk, fabsf(v)); }
+    acc = wave_sum_f64(acc);
+    pk = wave_max_f32(pk);
+    if ((threadIdx.x & 63) == 0) { s_s[threadIdx.x >> 6] = acc; s_p[threadIdx.x >> 6] = pk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sumsq[s] = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+        peak[s] = fmaxf(fmaxf(s_p[0], s_p[1]), fmaxf(s_p[2], s_p[3]));
+    }
+}
+
+extern "C" int ac_segment_sumsq_peak(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end,
+                                      int n_seg, double* sumsq, float* peak, void* stream) {
+    AC_REQUIRE(ctx && x && seg_start && seg_end && sumsq && peak, "null pointer");
+    AC_REQUIRE(n > 0 && n_seg > 0, "sizes must be positive");
+    hipLaunchKernelGGL(k_segment_sumsq_peak, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, x, seg_start, seg_end, sumsq, peak);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

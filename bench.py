@@ -187,6 +187,7 @@ def main() -> None:
     unet_ms = stft_ms = istft_ms = 0.0
     items = 0
     phases = {"separate_s": 0.0, "detect_s": 0.0, "finalize_s": 0.0}
+    policy_s = 0.0
     summaries = []
     t0 = time.perf_counter()
     for step in range(args.steps):
@@ -197,6 +198,7 @@ def main() -> None:
         items += int(st.get("n_items", 0))
         for k in phases:
             phases[k] += res["timings"].get(k, 0.0)
+        policy_s += float(res.get("timings_policy_s", 0.0))
         summaries.append(batch.summarize(rank * args.steps + step, res["sample_boundaries"], args.track_seconds,
                                          {"step_s": time.perf_counter() - ts}))
     torch.cuda.synchronize()
@@ -240,9 +242,11 @@ def main() -> None:
             "phases_ms_per_step": {"separate": round(phases["separate_s"] / args.steps * 1e3, 2),
                                    "detect": round(phases["detect_s"] / args.steps * 1e3, 2),
                                    "finalize": round(phases["finalize_s"] / args.steps * 1e3, 2),
+                                   "boundary_policy": round(policy_s / args.steps * 1e3, 2),
                                    "mdx_stft": round(stft_ms / args.steps, 2), "unet": round(unet_ms / args.steps, 2),
                                    "mdx_istft": round(istft_ms / args.steps, 2)},
             "n_boundaries": all_summaries[0]["n_boundaries"], "boundaries_sha1": all_summaries[0]["boundaries_sha1"],
+            "n_manifest_cuts": len(res.get("cuts_samples", [])), "segment_layout_applied": bool(res.get("segment_layout_applied", False)),
             "tracks_completed": len(all_summaries),
         }
         if world == 1:

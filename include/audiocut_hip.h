@@ -254,6 +254,27 @@ int ac_zero_crossing_rate(ac_ctx* ctx, const float* x, int64_t n, int frame_len,
 int ac_stft2048_spectral(ac_ctx* ctx, const float* x, int64_t n, int hop, double sr, double* centroid_out, float* ratio_out,
                          int64_t n_frames, void* stream);
 
+/* ---- post-path boundary policy ------------------------------------------------------------ */
+
+/* `_classify_segments_vocal_presence` (core/seamless_splitter.py:2335-2342): librosa.feature.rms(y=segment, frame, hop) of
+ * every segment [seg_start[s], seg_end[s]) in one launch; a frame sees zeros outside its own segment (centred, constant
+ * padding).  frame_off[s] = index of segment s's first frame in `out` (frame_off[n_seg] = n_frames); segment s has
+ * 1 + (seg_end - seg_start) / hop frames. */
+int ac_segment_frame_rms(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end,
+                         const int64_t* frame_off, int n_seg, int frame, int hop, float* out, int64_t n_frames, void* stream);
+/* `_refine_boundaries_local_valley` (core/seamless_splitter.py:2646-2661): for boundary c the window [c - radius, c + radius)
+ * clipped to the signal, float64 'valid' moving mean of x^2 over `win`, dB = 20 log10(sqrt(mean + 1e-12) + 1e-12);
+ * orig_db[k] = dB at clip(c - start - win/2), min_db / min_idx[k] = first minimum (index into the 'valid' series;
+ * -1 when the window is not longer than `win`). */
+int ac_local_valley(ac_ctx* ctx, const float* x, int64_t n, const int64_t* centers, int k, int radius, int win, double* orig_db,
+                    double* min_db, int64_t* min_idx, void* stream);
+
+/* per-segment sum of x^2 (float64) and peak |x| over [seg_start[s], seg_end[s]) (host bounds inside [0, n]):
+ * `_merge_short_weak_human_tails_into_following_music` stats (core/seamless_splitter.py:2179-2196) and the classifier's
+ * short-segment branch (:2349-2358). */
+int ac_segment_sumsq_peak(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end, int n_seg,
+                          double* sumsq, float* peak, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score

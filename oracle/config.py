@@ -63,12 +63,14 @@ _CONFIG: Dict[str, Any] = {
     },
     "quality_control": {
         "min_split_gap": 1.2, "segment_min_duration": 2.0, "segment_max_duration": 18.0,
-        "pure_music_min_duration": 6.0, "segment_vocal_threshold_db": -50.0,
+        "pure_music_min_duration": 6.0, "segment_vocal_threshold_db": -50.0, "segment_min_mix_piece": 2.0,
+        "local_boundary_refine": {"enable": True, "search_radius_ms": 500, "window_ms": 5, "min_drop_db": 5.0},
         "enforce_quiet_cut": {
             "enable": True, "win_ms": 80, "guard_db": 1.5, "search_right_ms": 450,
             "floor_percentile": 0.5, "floor_db_override": None,
         },
     },
+    "segment_layout": {"enable": True, "micro_merge_s": 2.0, "soft_min_s": 5.0, "soft_max_s": 12.0, "min_gap_s": 1.0, "beat_snap_ms": 50},
     "vpbd": {
         "enabled": True, "candidate_pool": "unified", "candidate_debug_json": True, "breath_score_scale": 0.6,
         "beat_candidates": {"enable": True, "bars_per_cut": 2, "base_score": 0.3},

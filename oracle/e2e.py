@@ -64,11 +64,12 @@ class TrackResult:
     markers: Dict
     confidence: float
     timings: Dict[str, float] = field(default_factory=dict)
+    policy: Optional[object] = None           # oracle.layout.PolicyResult: the manifest-facing cuts after seamless_splitter.py:521-669
 
 
 def detect_and_finalize(mix: np.ndarray, vocal: np.ndarray, sr: int, cache: Optional[FT.FeatureCache],
                         vad_segments: Optional[List[Dict[str, float]]], markers: Optional[Dict] = None,
-                        timings: Optional[Dict[str, float]] = None):
+                        timings: Optional[Dict[str, float]] = None, policy_out: Optional[list] = None):
     """seamless_splitter.py:413-481 for mode v2.2_mdd."""
     t0 = time.perf_counter()
     pauses = D.detect_pure_vocal_pauses(vocal, sr, enable_mdd_enhancement=True, original_audio=mix,
@@ -87,6 +88,7 @@ def detect_and_finalize(mix: np.ndarray, vocal: np.ndarray, sr: int, cache: Opti
                 cands.append((float(t), 1.0))
                 protected.add(int(round(t * sr)))
         refined = finalize_and_filter_cuts(cands, mix, vocal, sr)
+        suppressed = [(float(c.t), float(c.score)) for c in (refined.suppressed or [])]
         bounds = set(refined.sample_boundaries)
         for s in protected:                      # seamless_splitter.py:501-508
             s = int(min(max(s, 0), len(mix)))
@@ -95,10 +97,17 @@ def detect_and_finalize(mix: np.ndarray, vocal: np.ndarray, sr: int, cache: Opti
         bounds = sorted(bounds)
     else:   # seamless_splitter.py:421-433: no candidates -> single segment
         bounds = [0, len(mix)]
+        suppressed = None
     t2 = time.perf_counter()
     if timings is not None:
         timings["detect_s"] = t1 - t0
         timings["finalize_s"] = t2 - t1
+    if policy_out is not None and suppressed is not None:       # seamless_splitter.py:521-669 (not reached on the single-segment exit)
+        from . import layout as LY
+        policy_out.append(LY.apply_boundary_policy(bounds, vocal, len(mix), sr, suppressed=suppressed,
+                                                   rms_series=None if cache is None else cache.rms_series,
+                                                   hop_s=0.05 if cache is None else cache.hop_s,
+                                                   beat_times=None if cache is None else cache.beat_times))
     return pauses, cands, bounds
 
 
@@ -123,5 +132,6 @@ def run_track(mix: np.ndarray, sr: int, weights, *, vad_fn=None, n_levels: int =
     conf = D.estimate_confidence(vocal, inst, mix)
     markers = D.vocal_presence_markers(vocal, sr)
     timings["separate_s"] = time.perf_counter() - t0
-    pauses, cands, bounds = detect_and_finalize(mix, vocal, sr, cache, vad_segments, markers, timings)
-    return TrackResult(bounds, pauses, cands, vocal, inst, cache, vad_segments, markers, conf, timings)
+    pol: list = []
+    pauses, cands, bounds = detect_and_finalize(mix, vocal, sr, cache, vad_segments, markers, timings, policy_out=pol)
+    return TrackResult(bounds, pauses, cands, vocal, inst, cache, vad_segments, markers, conf, timings, pol[0] if pol else None)

@@ -327,6 +327,113 @@ def golden_dormant_branch() -> None:
         cm.reset_runtime_config(); OCfg.reset_runtime_config()
 
 
+from audio_cut_amd.testing.policy_inputs import policy_case as _policy_case, random_layout_case as _random_layout_case  # noqa: E402
+
+
+def golden_boundary_policy() -> None:
+    """classification, layout refiner, local-valley refinement, weak-tail merge and sample-level
+    split of the reference (`seamless_splitter.py:521-669`, `segment_layout_refiner.py`) against oracle.layout."""
+    from audio_cut.analysis.features_cache import TrackFeatureCache
+    from audio_cut.cutting import segment_layout_refiner as rl
+    from audio_cut.cutting.refine import CutPoint
+    from vocal_smart_splitter.core import seamless_splitter as ss
+    from vocal_smart_splitter.utils.config_manager import get_config as rget
+    from oracle import layout as OL
+    out = {}
+    rng = np.random.default_rng(77)
+    # (1) the layout refiner alone on random segmentations (durations 0.3-25 s, both kinds, suppressed points, beats)
+    n_checked = 0
+    for case in range(60):
+        edges, kinds, rms, hop_s, beats, supp, cfg_kwargs, midpoint = _random_layout_case(rng, case)
+        k = len(kinds); total = float(edges[-1]); frames = len(rms)
+        cache = TrackFeatureCache(sr=SR, hop_length=int(SR * hop_s), hop_s=hop_s, duration_s=total, rms_series=rms,
+                                  spectral_flatness=np.zeros(frames, np.float32), onset_envelope=np.zeros(frames, np.float32),
+                                  onset_strength=np.zeros(frames, np.float32), onset_frames=np.zeros(0, np.int64), rms_max=float(rms.max()),
+                                  onset_max=0.0, bpm_features=None, tempo_curve=None, beat_times=beats, global_mdd=0.5,
+                                  mdd_series=np.zeros(frames, np.float32))
+        segs = [rl.Segment(float(edges[i]), float(edges[i + 1]), kinds[i]) for i in range(k)]
+        rres = rl.refine_layout(segs, [], config=rl.LayoutConfig(**cfg_kwargs), sample_rate=SR,
+                                suppressed_cut_points=[CutPoint(t=t, score=sc) for t, sc in supp], features=cache,
+                                allow_midpoint_fallback=midpoint)
+        osegs, osupp, _ = OL.refine_layout([[float(edges[i]), float(edges[i + 1]), kinds[i]] for i in range(k)], OL.LayoutConfig(**cfg_kwargs),
+                                          supp, rms, hop_s, beats, midpoint_fallback=midpoint)
+        assert [(s.start, s.end, s.kind) for s in rres.segments] == [(s[0], s[1], s[2]) for s in osegs], case
+        assert [(float(p.t), float(p.score)) for p in rres.suppressed_points] == [(float(t), float(sc)) for t, sc in osupp], case
+        n_checked += 1
+        if case < 12:
+            out[f"layout{case}_in"] = np.array([[edges[i], edges[i + 1], 1.0 if kinds[i] == "human" else 0.0] for i in range(k)])
+            out[f"layout{case}_rms"] = rms; out[f"layout{case}_supp"] = np.array(supp)
+            out[f"layout{case}_cfg"] = np.array([cfg_kwargs[x] for x in ("micro_merge_s", "soft_min_s", "soft_max_s", "min_gap_s", "beat_snap_ms")] + [float(midpoint)])
+            out[f"layout{case}_out"] = np.array([[s.start, s.end, 1.0 if s.kind == "human" else 0.0] for s in rres.segments])
+    # (2) the sample-domain steps on a synthetic stem, composed in the reference's order (`seamless_splitter.py:521-669`)
+    fake = types.SimpleNamespace(sample_rate=SR)
+    fake._classify_segments_vocal_presence = lambda *a, **k: ss.SeamlessSplitter._classify_segments_vocal_presence(fake, *a, **k)
+    for seed in (11, 12):
+        voc, cuts, rms, hop_s, beats, supp = _policy_case(seed)
+        n = len(voc)
+        cache = TrackFeatureCache(sr=SR, hop_length=int(SR * hop_s), hop_s=hop_s, duration_s=n / SR, rms_series=rms,
+                                  spectral_flatness=np.zeros_like(rms), onset_envelope=np.zeros_like(rms), onset_strength=np.zeros_like(rms),
+                                  onset_frames=np.zeros(0, np.int64), rms_max=float(rms.max()), onset_max=0.0, bpm_features=None,
+                                  tempo_curve=None, beat_times=beats, global_mdd=0.5, mdd_series=np.zeros_like(rms))
+        flags = fake._classify_segments_vocal_presence(voc, cuts)
+        oflags, _ = OL.classify_segments(voc, cuts, SR)
+        assert flags == oflags
+        # layout config exactly as `:533-556` derives it
+        raw = dict(rget("segment_layout", {}) or {})
+        micro = rget("quality_control.segment_min_mix_piece", None)
+        if micro is not None:
+            raw.setdefault("micro_merge_s", float(micro)); raw.setdefault("enable", bool(float(micro) > 0.0))
+        smax = rget("quality_control.segment_max_duration", None)
+        if smax is not None:
+            raw.setdefault("soft_max_s", float(smax))
+        raw.setdefault("min_gap_s", float(rget("quality_control.min_split_gap", 1.0)))
+        raw.setdefault("beat_snap_ms", float(rget("segment_layout.beat_snap_ms", 0.0) or 0.0))
+        lcfg = rl.derive_layout_config(raw, cache, sample_rate=SR)
+        ocfg = OL.layout_config_from_settings()
+        assert (lcfg.enable, lcfg.micro_merge_s, lcfg.soft_min_s, lcfg.soft_max_s, lcfg.min_gap_s, lcfg.beat_snap_ms) == \
+               (ocfg.enable, ocfg.micro_merge_s, ocfg.soft_min_s, ocfg.soft_max_s, ocfg.min_gap_s, ocfg.beat_snap_ms)
+        bsec = [c / float(SR) for c in cuts]
+        lres = rl.refine_layout([rl.Segment(bsec[i], bsec[i + 1], "human" if flags[i] else "music") for i in range(len(bsec) - 1)], [],
+                                config=lcfg, sample_rate=SR, suppressed_cut_points=[CutPoint(t=t, score=sc) for t, sc in supp], features=cache)
+        lb = [lres.segments[0].start] + [sg.end for sg in lres.segments]
+        upd = [max(0, min(int(round(t * SR)), n)) for t in lb]
+        upd[0] = 0; upd[-1] = n
+        upd = sorted(set(upd))
+        applied = upd != cuts
+        cur = upd
+        flags = fake._classify_segments_vocal_presence(voc, cur)
+        lcl = rget("quality_control.local_boundary_refine", {}) or {}
+        if lcl.get("enable") and len(cur) >= 2:
+            ref = ss.SeamlessSplitter._refine_boundaries_local_valley(fake, cur, voc, lcl, min_gap_s=float(rget("quality_control.min_split_gap", 1.0)))
+            oref = OL.refine_local_valley(cur, voc, SR, lcl, float(rget("quality_control.min_split_gap", 1.0)))
+            assert list(ref) == list(oref)
+            if list(ref) != cur:
+                cur = list(ref); applied = True
+                flags = fake._classify_segments_vocal_presence(voc, cur)
+        c2, f2, _ = ss.SeamlessSplitter._merge_short_weak_human_tails_into_following_music(
+            fake, cur, flags, [], voc, min_duration_s=float(lcfg.soft_min_s or 0.0), layout_applied=applied)
+        oc2, of2 = OL.merge_weak_human_tails(cur, flags, voc, SR, float(lcfg.soft_min_s or 0.0), applied)
+        assert (list(c2), list(f2)) == (oc2, of2)
+        if list(c2) != cur:
+            cur, flags, applied = list(c2), list(f2), True
+        fake2 = object.__new__(ss.SeamlessSplitter); fake2.sample_rate = SR
+        pieces, mflags, _ = fake2._split_at_sample_level(np.arange(n, dtype=np.int64), cur, segment_flags=flags, debug_entries=None)
+        ranges = [(int(p[0]), int(p[-1]) + 1) for p in pieces]
+        oranges, omflags = OL.split_at_sample_level(n, cur, flags, SR)
+        assert ranges == [tuple(r) for r in oranges] and list(mflags) == list(omflags)
+        whole = OL.apply_boundary_policy(cuts, voc, n, SR, suppressed=supp, rms_series=rms, hop_s=hop_s, beat_times=beats)
+        assert whole.cuts == cur and whole.flags == list(mflags) and whole.pieces == ranges and whole.layout_applied == applied, seed
+        out[f"policy{seed}_cuts_in"] = np.asarray(cuts, dtype=np.int64)
+        out[f"policy{seed}_cuts_out"] = np.asarray(cur, dtype=np.int64)
+        out[f"policy{seed}_flags"] = np.asarray(mflags, dtype=np.int8)
+        out[f"policy{seed}_pieces"] = np.asarray(ranges, dtype=np.int64)
+        out[f"policy{seed}_applied"] = np.asarray([int(applied)])
+        out[f"policy{seed}_supp"] = np.asarray(supp)
+        print(f"  boundary policy [seed {seed}]: {len(cuts)} cuts -> {len(cur)}; layout_applied={applied}")
+    print(f"  layout refiner: {n_checked} random segmentations identical")
+    _save("boundary_policy.npz", **out)
+
+
 def golden_vpbd() -> None:
     import tempfile
     from vocal_smart_splitter.core.vocal_phrase_boundary_detector import VocalPhraseBoundaryDetector as RefVPBD
@@ -382,5 +489,6 @@ if __name__ == "__main__":
     golden_chunk_vad()
     golden_features_and_detector()
     golden_dormant_branch()
+    golden_boundary_policy()
     golden_vpbd()
     print("all goldens generated; oracle pinned against the reference's control logic")

@@ -179,6 +179,11 @@ def test_full_path_separate_detect_against_oracle(hip_ctx):
     assert sep.quality_metrics["vocal_presence_cut_points_sec"] == ref.markers["vocal_presence_cut_points_sec"]
     _assert_pauses_equal(res["pauses"], ref.pauses)
     assert res["sample_boundaries"] == ref.sample_boundaries
+    # the manifest-facing cuts after classification / layout / local valley / weak-tail merge
+    assert res["cuts_samples"] == ref.policy.cuts
+    assert res["segment_vocal_flags"] == ref.policy.flags
+    assert [tuple(p) for p in res["segment_spans"]] == ref.policy.pieces
+    assert res["segment_layout_applied"] == ref.policy.layout_applied
 
 
 def test_vpbd_acoustic_mode_against_oracle(hip_ctx):
