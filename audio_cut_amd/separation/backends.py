@@ -112,12 +112,17 @@ class MDX23HipBackend(IVocalSeparatorBackend):
         return self._sr
 
     def load_model(self) -> None:
-        """Weights: an explicit name->ndarray dict, else `<model_dir>/<model>.npz` if the operator exported
-        one, else seeded synthetic weights of the Kim_Vocal_1 architecture (the ONNX file cannot be
-        fetched offline; see tfc_tdf.py)."""
+        """Weights: an explicit name->ndarray dict, else `<model_dir>/<model_filename>` (the ONNX file the reference
+        hands to onnxruntime, `backends.py:222-255`; its initializers are read by separation/onnx_weights.py), else
+        `<model_dir>/<model>.npz`, else seeded synthetic weights of the Kim_Vocal_1 architecture (the ONNX file cannot
+        be fetched offline; see tfc_tdf.py)."""
         if self._ctx is None:
             self._ctx = _native.Context(self._device)
         w = self._weights
+        if w is None and self._model_dir is not None and (self._model_dir / self._model_name).exists():
+            from .onnx_weights import load_tfc_tdf_weights
+            w = load_tfc_tdf_weights(self._model_dir / self._model_name, self._spec)
+            logger.info("[MDX23Hip] loaded %d tensors from %s", len(w), self._model_dir / self._model_name)
         if w is None and self._model_dir is not None:
             cand = self._model_dir / (Path(self._model_name).stem + ".npz")
             if cand.exists():
