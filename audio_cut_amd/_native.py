@@ -90,6 +90,8 @@ SIGNATURES = {
     "ac_segment_frame_rms": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
     "ac_segment_sumsq_peak": (C.c_int, [_P, _P, _I64, _P, _P, _I, _P, _P, _P]),
     "ac_local_valley": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "ac_resample_poly": (C.c_int, [_P, _P, _I64, _I, _I, _P, _I64, _I64, _P, _I64, _P]),
+    "ac_pack_pcm24": (C.c_int, [_P, _P, _I64, _P, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -224,6 +226,38 @@ class Context:
         _check(self.lib.ac_yin_f0(self._h, _ptr(x), n, frame_length, hop, min_period, max_period, float(threshold),
                                   _ptr(period), _ptr(cmnd), nf, _stream()))
         return float(sr) / period.cpu().numpy(), cmnd
+
+    # -- loader / exporter ---------------------------------------------------
+    def resample_poly(self, x: torch.Tensor, up: int, down: int) -> torch.Tensor:
+        """scipy.signal.resample_poly(x, up, down) on the device (default Kaiser(5.0) design, zero padding)."""
+        import math
+        import scipy.signal
+        self._chk_f32(x)
+        g = math.gcd(int(up), int(down))
+        up, down = int(up) // g, int(down) // g
+        if up == down == 1:
+            return x.clone()
+        n = x.numel()
+        n_out = n * up
+        n_out = n_out // down + bool(n_out % down)
+        half_len = 10 * max(up, down)
+        h = scipy.signal.firwin(2 * half_len + 1, 1.0 / max(up, down), window=("kaiser", 5.0)).astype(np.float32)
+        h *= up
+        n_pre_pad = down - half_len % down
+        n_pre_remove = (half_len + n_pre_pad) // down
+        h = np.concatenate((np.zeros(n_pre_pad, dtype=np.float32), h))
+        hd = self.to_device(h)
+        out = torch.empty(n_out, dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_resample_poly(self._h, _ptr(x), n, up, down, _ptr(hd), h.size, n_pre_remove, _ptr(out), n_out, _stream()))
+        return out
+
+    def pack_pcm24(self, x: torch.Tensor) -> np.ndarray:
+        """float32 device track -> host uint8 array of 3 * n little-endian PCM_24 bytes."""
+        self._chk_f32(x)
+        n = x.numel()
+        out = torch.empty(3 * n + 3, dtype=torch.uint8, device=self.device)
+        _check(self.lib.ac_pack_pcm24(self._h, _ptr(x), n, _ptr(out), _stream()))
+        return out[: 3 * n].cpu().numpy()
 
     # -- post-path boundary policy (SURVEY.md 8(f) row 1) ----------------------------------------------
     def segment_frame_rms(self, x: torch.Tensor, seg_start: np.ndarray, seg_end: np.ndarray, frame: int, hop: int):

@@ -87,7 +87,8 @@ class SeamlessSplitter:
         is_vpbd = mode in {"vpbd_acoustic", "vpbd_asr"}
         result: Dict = {"success": True, "mode": mode, "gpu_meta": dict(sep.gpu_meta or {}),
                         "separation_confidence": sep.separation_confidence, "backend_used": sep.backend_used,
-                        "vad_segments": sep.vad_segments, "feature_cache": cache}
+                        "vad_segments": sep.vad_segments, "feature_cache": cache,
+                        "vocal_track": vocal_track, "instrumental_track": sep.instrumental_track, "device_state": state}
         if is_vpbd:
             # reference `:362-408`.  The smart_cut intent / AutoProfile runtime overrides applied at `:349` are
             # product configuration policy (out of scope): VPBD runs on the base configuration.

@@ -1,0 +1,73 @@
+// Loader / exporter kernels.
+//  * ac_resample_poly: rational-rate polyphase FIR resampling of a resident track (the loader's 48 kHz -> 44.1 kHz and
+//    the VAD's 44.1 kHz -> 16 kHz, `audio_processor.py:45-49`, `vocal_pause_detector.py:189`).  The reference's
+//    resampler is soxr_hq through librosa, which is not available offline, so the parity definition of this row is
+//    scipy.signal.resample_poly(x, up, down) (Kaiser(5.0) windowed sinc, half length 10 * max(up, down), zero padding),
+//    whose filter the host designs with the very scipy calls and hands over already scaled and front-padded.
+//  * ac_pack_pcm24: float32 [-1, 1] -> little-endian 24-bit PCM, round-to-nearest-even of x * 8388607 (libsndfile's
+//    normalised float -> PCM_24 conversion behind soundfile.write(subtype="PCM_24"), `audio_export.py:109-111`), clipped
+//    instead of wrapped; four samples (12 bytes) per thread.
+#include "ac_common.h"
+
+__global__ __launch_bounds__(256) void k_resample_poly(const float* __restrict__ x, int64_t n, int up, int down,
+                                                       const float* __restrict__ h, int64_t hlen, int64_t n_pre_remove,
+                                                       float* __restrict__ out, int64_t n_out) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_out) return;
+    // y_full[M] = sum_q h[M * down - q * up] x[q], M = m + n_pre_remove
+    const int64_t i = (m + n_pre_remove) * (int64_t)down;
+    int64_t q_hi = i / up;                               // h index >= 0
+    if (q_hi > n - 1) q_hi = n - 1;
+    int64_t q_lo = (i - hlen + 1 + up - 1) / up;         // h index < hlen  (ceil division; i - hlen + 1 may be negative)
+    if (i - hlen + 1 <= 0) q_lo = 0;
+    double acc = 0.0;
+    for (int64_t q = q_lo; q <= q_hi; ++q) acc += (double)h[i - q * up] * (double)x[q];
+    out[m] = (float)acc;
+}
+
+extern "C" int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* h, int64_t hlen,
+                                 int64_t n_pre_remove, float* out, int64_t n_out, void* stream) {
+    AC_REQUIRE(ctx && x && h && out, "null pointer");
+    AC_REQUIRE(n > 0 && up > 0 && down > 0 && hlen > 0 && n_pre_remove >= 0 && n_out > 0, "sizes must be positive");
+    AC_REQUIRE((n_out + 255) / 256 < (1LL << 31), "output too long");
+    hipLaunchKernelGGL(k_resample_poly, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, up, down, h, hlen,
+                       n_pre_remove, out, n_out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+__device__ inline int pcm24(float v) {
+    const float s = rintf(v * 8388607.0f);               // lrintf under the default rounding mode: half to even
+    return s > 8388607.0f ? 8388607 : (s < -8388608.0f ? -8388608 : (int)s);
+}
+
+__global__ __launch_bounds__(256) void k_pack_pcm24(const float* __restrict__ x, int64_t n, unsigned char* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;       // quad of samples
+    const int64_t s0 = q * 4;
+    if (s0 >= n) return;
+    if (s0 + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(x + s0);
+        const unsigned a = (unsigned)pcm24(v.x) & 0xFFFFFF, b = (unsigned)pcm24(v.y) & 0xFFFFFF;
+        const unsigned c = (unsigned)pcm24(v.z) & 0xFFFFFF, d = (unsigned)pcm24(v.w) & 0xFFFFFF;
+        unsigned* o = reinterpret_cast<unsigned*>(out + s0 * 3);     // 12-byte aligned: s0 % 4 == 0
+        o[0] = a | (b << 24);
+        o[1] = (b >> 8) | (c << 16);
+        o[2] = (c >> 16) | (d << 8);
+    } else {
+        for (int64_t s = s0; s < n; ++s) {
+            const unsigned a = (unsigned)pcm24(x[s]) & 0xFFFFFF;
+            out[s * 3] = (unsigned char)a; out[s * 3 + 1] = (unsigned char)(a >> 8); out[s * 3 + 2] = (unsigned char)(a >> 16);
+        }
+    }
+}
+
+extern "C" int ac_pack_pcm24(ac_ctx* ctx, const float* x, int64_t n, unsigned char* out, void* stream) {
+    AC_REQUIRE(ctx && x && out, "null pointer");
+    AC_REQUIRE(n > 0, "n must be positive");
+    const int64_t quads = (n + 3) / 4;
+    AC_REQUIRE((quads + 255) / 256 < (1LL << 31), "input too long");
+    AC_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)out) & 3) == 0, "x 16-byte and out 4-byte aligned");
+    hipLaunchKernelGGL(k_pack_pcm24, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

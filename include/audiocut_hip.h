@@ -275,6 +275,18 @@ int ac_local_valley(ac_ctx* ctx, const float* x, int64_t n, const int64_t* cente
 int ac_segment_sumsq_peak(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end, int n_seg,
                           double* sumsq, float* peak, void* stream);
 
+/* ---- loader / exporter ----------------------------------------------------------- */
+
+/* Rational-rate polyphase resampling = scipy.signal.resample_poly(x, up, down) (the offline parity definition of the
+ * loader's `librosa.load(sr=44100)` at audio_processor.py:45-49 and the VAD's 16 kHz resample at
+ * vocal_pause_detector.py:189, whose soxr_hq filter is not available).  h [hlen] float32 = firwin(...) * up with the
+ * n_pre_pad leading zeros scipy adds; out[m] = sum_q h[(m + n_pre_remove) * down - q * up] x[q], float64 accumulation. */
+int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* h, int64_t hlen, int64_t n_pre_remove,
+                     float* out, int64_t n_out, void* stream);
+/* float32 -> little-endian PCM_24 (rint(x * 8388607), clipped): soundfile.write(subtype="PCM_24") behind
+ * vocal_smart_splitter/utils/audio_export.py:109-111.  out [3 * n] bytes. */
+int ac_pack_pcm24(ac_ctx* ctx, const float* x, int64_t n, unsigned char* out, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score
