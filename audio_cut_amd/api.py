@@ -118,12 +118,13 @@ def separate_and_segment(*, input_uri: str, export_dir: str, mode: Optional[str]
             audio = audio_dev.cpu().numpy()
         res = splitter.split_track(audio, mode=resolved_mode, audio_dev=audio_dev)
         layout_cfg = dict(_config.get_config("segment_layout", {}) or {})
-        plan = _normalize_export_plan(export_types)
+        single = bool(res.get("single_segment"))            # `_create_single_segment_result`: only the mix, no duration tag
+        plan = _normalize_export_plan(export_types) if (export_types or not single) else ["mix_segments"]
         cuts = [int(c) for c in res.get("cuts_samples", res["sample_boundaries"])]
         spans = [tuple(sp) for sp in res.get("segment_spans", list(zip(cuts[:-1], cuts[1:])))]
         flags = list(res.get("segment_vocal_flags", [True] * len(spans)))
         durations = [(hi - lo) / float(sr) for lo, hi in spans]
-        dmap = {i: d for i, d in enumerate(durations)}
+        dmap = None if single else {i: d for i, d in enumerate(durations)}
         exp = ExportResult()
         exporter = SegmentExporter(sr)
         state = res.get("device_state") or {}

@@ -72,6 +72,8 @@ class SeamlessSplitter:
         if mode not in self.SUPPORTED_MODES:
             raise NotImplementedError(f"mode {mode!r}: only the v2.2_mdd / v2.1 path is built this round")
         sr = self.sample_rate
+        if original_audio is None or len(original_audio) == 0:
+            raise ValueError("split_track needs a non-empty mono track")
         t0 = time.perf_counter()
         sep: SeparationResult = self.separator.separate_for_detection(original_audio, gpu_context=None, audio_dev=audio_dev)
         t_sep = time.perf_counter() - t0
@@ -105,6 +107,7 @@ class SeamlessSplitter:
             if not cut_candidates:
                 result.update({"sample_boundaries": [0, len(original_audio)], "note": "no_vpbd_candidates",
                                "timings": {"separate_s": t_sep, "detect_s": t_det, "finalize_s": 0.0}})
+                result.update(self._single_segment_fields(vocal_track, len(original_audio), state.get("vocal")))
                 return result
             t2 = time.perf_counter()
         else:
@@ -116,6 +119,7 @@ class SeamlessSplitter:
             if not pauses:      # `:421-433`: single segment
                 result.update({"sample_boundaries": [0, len(original_audio)], "note": "no_pause_candidates",
                                "timings": {"separate_s": t_sep, "detect_s": t_det, "finalize_s": 0.0}})
+                result.update(self._single_segment_fields(vocal_track, len(original_audio), state.get("vocal")))
                 return result
             t2 = time.perf_counter()
             cut_candidates = [(float(p.cut_point), float(p.confidence)) for p in pauses]
@@ -155,6 +159,18 @@ class SeamlessSplitter:
         return result
 
     # ------------------------------------------------------------------------------------------
+    def _single_segment_fields(self, vocal_track: np.ndarray, n_samples: int, vocal_dev=None) -> Dict:
+        """`_create_single_segment_result` (`:2682-2747`): one segment labelled by `_estimate_vocal_presence` (`:2404-2410`)."""
+        self._last_guard_adjustments_raw = []
+        self._last_suppressed_cut_points = []
+        flags = self._classify_segments_vocal_presence(vocal_track, [0, len(vocal_track)], vocal_dev=vocal_dev) \
+            if (vocal_track is not None and getattr(vocal_track, "size", 0)) else []
+        has_vocal = bool(flags[0]) if flags else False
+        sr = float(self.sample_rate)
+        return {"cuts_samples": [0, int(n_samples)], "cuts_sec": [0.0, n_samples / sr], "segment_vocal_flags": [has_vocal],
+                "segment_spans": [(0, int(n_samples))], "segment_durations": [n_samples / sr], "segment_layout_applied": False,
+                "suppressed_cut_points_sec": [], "single_segment": True}
+
     # ---- post-path boundary policy (SURVEY.md 8(f) row 1; reference `seamless_splitter.py:521-669`) -----------
     def _vocal_on_device(self, vocal_audio: np.ndarray, vocal_dev=None):
         return vocal_dev if vocal_dev is not None else self._context().to_device(np.ascontiguousarray(vocal_audio, dtype=np.float32))

@@ -313,3 +313,30 @@ def test_dormant_multifeature_branch_against_oracle_and_golden(hip_ctx, golden_d
             assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-3, atol=1e-3)                      # confidence (a float score)
     finally:
         PCFG.restore(saved); OCFG.reset_runtime_config()
+
+
+def test_degenerate_tracks(hip_ctx, tmp_path):
+    """Empty / sub-chunk / silent / constant inputs: the single-segment exits of the reference (`seamless_splitter.py:421-433`,
+    `_create_single_segment_result`) and a refusal for an empty track, never a device fault."""
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=0), ctx=hip_ctx)
+    backend.load_model()
+    sp = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend))
+    cases = {"silence": np.zeros(12 * SR, np.float32), "one_second": signals.c2_song(1.0, seed=1),
+             "12345_samples": signals.c2_song(0.28, seed=1)[:12345], "dc": np.full(9 * SR, 0.3, np.float32)}
+    for name, x in cases.items():
+        for mode in ("v2.2_mdd", "vpbd_acoustic"):
+            r = sp.split_track(x, mode=mode)
+            assert r["sample_boundaries"] == [0, len(x)] and r["cuts_samples"] == [0, len(x)], (name, mode)
+            assert r["note"] in ("no_pause_candidates", "no_vpbd_candidates") and r["single_segment"] is True
+            assert r["segment_vocal_flags"] == [False] if name in ("silence",) else len(r["segment_vocal_flags"]) == 1
+    for x in (signals.c2_song(10.0, seed=2), signals.c2_song(23.7, seed=3)[:-7]):     # exactly one chunk; ragged multi-chunk
+        r = sp.split_track(x)
+        c = r["cuts_samples"]
+        assert c[0] == 0 and c[-1] == len(x) and c == sorted(set(c)) and len(r["segment_vocal_flags"]) == len(r["segment_spans"])
+        assert sum(hi - lo for lo, hi in r["segment_spans"]) == len(x)
+    with pytest.raises(ValueError):
+        sp.split_track(np.zeros(0, np.float32))
