@@ -279,10 +279,14 @@ class Context:
         self._chk_f32(x)
         a = self.to_device(np.asarray(seg_start, dtype=np.int64)); b = self.to_device(np.asarray(seg_end, dtype=np.int64))
         k = a.numel()
-        ss = torch.empty(k, dtype=torch.float64, device=self.device)
-        pk = torch.empty(k, dtype=torch.float32, device=self.device)
+        ss = torch.empty((k, 16), dtype=torch.float64, device=self.device)
+        pk = torch.empty((k, 16), dtype=torch.float32, device=self.device)
         _check(self.lib.ac_segment_sumsq_peak(self._h, _ptr(x), x.numel(), _ptr(a), _ptr(b), k, _ptr(ss), _ptr(pk), _stream()))
-        return ss.cpu().numpy(), pk.cpu().numpy()
+        parts = ss.cpu().numpy()
+        total = np.zeros(k, dtype=np.float64)
+        for p in range(16):                       # fixed order: deterministic
+            total += parts[:, p]
+        return total, pk.cpu().numpy().max(axis=1)
 
     def local_valley(self, x: torch.Tensor, centers: np.ndarray, radius: int, win: int):
         """(orig_db, min_db, min_idx) per boundary, host arrays (see ac_local_valley)."""

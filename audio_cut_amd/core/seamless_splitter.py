@@ -196,11 +196,25 @@ class SeamlessSplitter:
         a = np.clip(np.asarray(cut_points[:-1], dtype=np.int64), 0, n)
         b = np.maximum(a, np.clip(np.asarray(cut_points[1:], dtype=np.int64), 0, n))
         hip = self._context()
-        dev = self._vocal_on_device(vocal_audio, vocal_dev)
-        long_ix = np.flatnonzero((b - a) >= frame_length)
-        frames = dict(zip(long_ix.tolist(), hip.segment_frame_rms(dev, a[long_ix], b[long_ix], frame_length, hop))) if long_ix.size else {}
-        short_ix = np.flatnonzero(((b - a) > 0))
-        sumsq = dict(zip(short_ix.tolist(), hip.segment_sumsq_peak(dev, a[short_ix], b[short_ix])[0])) if short_ix.size else {}
+        # segments already measured in this policy pass (the three classification rounds of `_apply_boundary_policy` mostly
+        # see the same segments) come from the cache; the rest go to the GPU in two launches
+        cache = getattr(self, "_segment_measure_cache", None)
+        key = [(int(a[i]), int(b[i])) for i in range(n_seg)]
+        need = [i for i in range(n_seg) if b[i] > a[i] and (cache is None or key[i] not in cache)]
+        measured = {}
+        if need:
+            dev = self._vocal_on_device(vocal_audio, vocal_dev)
+            nd = np.asarray(need, dtype=np.int64)
+            ss = hip.segment_sumsq_peak(dev, a[nd], b[nd])[0]
+            long_ix = nd[(b[nd] - a[nd]) >= frame_length]
+            fr = dict(zip(long_ix.tolist(), hip.segment_frame_rms(dev, a[long_ix], b[long_ix], frame_length, hop))) if long_ix.size else {}
+            for j, i in enumerate(need):
+                measured[key[i]] = (float(ss[j]), fr.get(i))
+            if cache is not None:
+                cache.update(measured)
+        look = (lambda k: cache.get(k)) if cache is not None else (lambda k: measured.get(k))
+        frames = {i: look(key[i])[1] for i in range(n_seg) if b[i] > a[i] and look(key[i])[1] is not None}
+        sumsq = {i: look(key[i])[0] for i in range(n_seg) if b[i] > a[i]}
         flags: List[bool] = []
         debug: List[Dict] = []
         for i in range(n_seg):
@@ -370,6 +384,15 @@ class SeamlessSplitter:
         from ..cutting.segment_layout_refiner import Segment as LayoutSegment, derive_layout_config, refine_layout
         sr = self.sample_rate
         cuts = sorted(set(int(c) for c in bounds))
+        self._segment_measure_cache = {}
+        try:
+            return self._boundary_policy_steps(cuts, vocal_track, n_samples, cache, vocal_dev)
+        finally:
+            self._segment_measure_cache = None
+
+    def _boundary_policy_steps(self, cuts: List[int], vocal_track: np.ndarray, n_samples: int, cache, vocal_dev) -> Dict:
+        from ..cutting.segment_layout_refiner import Segment as LayoutSegment, derive_layout_config, refine_layout
+        sr = self.sample_rate
         flags = self._classify_segments_vocal_presence(vocal_track, cuts, vocal_dev=vocal_dev)
         raw = dict(get_config("segment_layout", {}) or {})
         micro = get_config("quality_control.segment_min_mix_piece", None)

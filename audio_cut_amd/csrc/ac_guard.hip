@@ -571,23 +571,27 @@ extern "C" int ac_local_valley(ac_ctx* ctx, const float* x, int64_t n, const int
 
 // (3) per-segment sum of squares (float64) and peak |x| for the weak-tail rule (`_merge_short_weak_human_tails_...`,
 //     seamless_splitter.py:2179-2196) and the short-segment branch of the classifier (:2349-2358).  One workgroup per
-//     segment, fixed-order tree reduction (deterministic).
+//     (segment, sixteenth), fixed-order tree reduction; the host adds the 16 partials of a segment in order (deterministic).
+#define SSP_PARTS 16
 __global__ __launch_bounds__(256) void k_segment_sumsq_peak(const float* __restrict__ x, const int64_t* __restrict__ seg_start,
-                                                            const int64_t* __restrict__ seg_end, double* __restrict__ sumsq,
-                                                            float* __restrict__ peak) {
+                                                            const int64_t* __restrict__ seg_end, double* __restrict__ part_sumsq,
+                                                            float* __restrict__ part_peak) {
+    // grid (segment, part): part p owns the p-th contiguous sixteenth of the segment; the host adds the parts in order
     __shared__ double s_s[4];
     __shared__ float s_p[4];
-    const int s = blockIdx.x;
+    const int s = blockIdx.x, part = blockIdx.y;
     const int64_t a = seg_start[s], b = seg_end[s];
+    const int64_t chunk = (b - a + SSP_PARTS - 1) / SSP_PARTS;
+    const int64_t lo = a + part * chunk, hi = (lo + chunk < b) ? lo + chunk : b;
     double acc = 0.0; float pk = 0.f;
-    for (int64_t i = a + threadIdx.x; i < b; i += 256) { const float v = x[i]; acc += (double)v * (double)v; pk = fmaxf(pk, fabsf(v)); }
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const float v = x[i]; acc += (double)v * (double)v; pk = fmaxf(pk, fabsf(v)); }
     acc = wave_sum_f64(acc);
     pk = wave_max_f32(pk);
     if ((threadIdx.x & 63) == 0) { s_s[threadIdx.x >> 6] = acc; s_p[threadIdx.x >> 6] = pk; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        sumsq[s] = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
-        peak[s] = fmaxf(fmaxf(s_p[0], s_p[1]), fmaxf(s_p[2], s_p[3]));
+        part_sumsq[(int64_t)s * SSP_PARTS + part] = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+        part_peak[(int64_t)s * SSP_PARTS + part] = fmaxf(fmaxf(s_p[0], s_p[1]), fmaxf(s_p[2], s_p[3]));
     }
 }
 
@@ -595,7 +599,7 @@ extern "C" int ac_segment_sumsq_peak(ac_ctx* ctx, const float* x, int64_t n, con
                                       int n_seg, double* sumsq, float* peak, void* stream) {
     AC_REQUIRE(ctx && x && seg_start && seg_end && sumsq && peak, "null pointer");
     AC_REQUIRE(n > 0 && n_seg > 0, "sizes must be positive");
-    hipLaunchKernelGGL(k_segment_sumsq_peak, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, x, seg_start, seg_end, sumsq, peak);
+    hipLaunchKernelGGL(k_segment_sumsq_peak, dim3((unsigned)n_seg, SSP_PARTS), dim3(256), 0, (hipStream_t)stream, x, seg_start, seg_end, sumsq, peak);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

@@ -280,14 +280,15 @@ def _snap_to_beats(segments: List[Segment], beat_snap_ms: float, *, features: Op
         return segments
     reach = beat_snap_ms / 1000.0
     segs = _copy(segments)
+    grid = np.asarray(beats, dtype=np.float64)
     for k in range(1, len(segs)):
         at = segs[k].start
-        near, dist = None, None
-        for bt in beats:
-            d = abs(float(bt) - at)
-            if d <= reach and (dist is None or d < dist):
-                near, dist = float(bt), d
-        if near is None or (near - segs[k - 1].start) < min_gap_s or (segs[k].end - near) < min_gap_s:
+        dist = np.abs(grid - at)
+        j = int(np.argmin(dist))                      # first nearest beat, as the reference's strict `<` scan keeps
+        if not dist[j] <= reach:
+            continue
+        near = float(grid[j])
+        if (near - segs[k - 1].start) < min_gap_s or (segs[k].end - near) < min_gap_s:
             continue
         segs[k - 1].end = near
         segs[k].start = near

@@ -269,7 +269,8 @@ int ac_segment_frame_rms(ac_ctx* ctx, const float* x, int64_t n, const int64_t* 
 int ac_local_valley(ac_ctx* ctx, const float* x, int64_t n, const int64_t* centers, int k, int radius, int win, double* orig_db,
                     double* min_db, int64_t* min_idx, void* stream);
 
-/* per-segment sum of x^2 (float64) and peak |x| over [seg_start[s], seg_end[s]) (host bounds inside [0, n]):
+/* per-segment sum of x^2 (float64) and peak |x| over [seg_start[s], seg_end[s]) (host bounds inside [0, n]) as 16
+ * partials per segment (sumsq / peak are [n_seg][16]; the caller adds / maxes them in order):
  * `_merge_short_weak_human_tails_into_following_music` stats (core/seamless_splitter.py:2179-2196) and the classifier's
  * short-segment branch (:2349-2358). */
 int ac_segment_sumsq_peak(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end, int n_seg,
