@@ -1,0 +1,36 @@
+"""Writes tests/golden/c2_full_oracle.npz: the CPU oracle's result on the full BASELINE configs[1] track (4-min C2 song,
+seed 2, seeded synthetic weights seed 0).  The oracle takes minutes on the CPU, so the GPU test compares against this
+fixture instead of re-running it (the same comparison, run live on the GPU box, is scratch/c2_full.py).
+Run from the repo root:  python tests/golden/make_c2_full.py"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights  # noqa: E402
+from audio_cut_amd.testing import signals  # noqa: E402
+from oracle import e2e as OE, refine as OR  # noqa: E402
+
+if __name__ == "__main__":
+    OR.LEGACY_PROMOTION = True
+    mix = signals.c2_song(240.0, seed=2)
+    w = synth_weights(TfcTdfSpec(), seed=0)
+    t0 = time.time()
+    ref = OE.run_track(mix, 44100, w)
+    print(f"oracle: {time.time() - t0:.1f} s, {len(ref.sample_boundaries)} boundaries, {len(ref.policy.cuts)} manifest cuts")
+    sec = 44100
+    nsec = len(mix) // sec
+    np.savez_compressed(ROOT / "tests" / "golden" / "c2_full_oracle.npz",
+                        sample_boundaries=np.asarray(ref.sample_boundaries, dtype=np.int64),
+                        cuts=np.asarray(ref.policy.cuts, dtype=np.int64), flags=np.asarray(ref.policy.flags, dtype=np.int8),
+                        pieces=np.asarray(ref.policy.pieces, dtype=np.int64),
+                        pause_cut_points=np.asarray([p.cut_point for p in ref.pauses], dtype=np.float64),
+                        vocal_rms_per_second=np.sqrt(np.mean(ref.vocal[: nsec * sec].reshape(nsec, sec).astype(np.float64) ** 2, axis=1)),
+                        vocal_head=ref.vocal[: 4 * sec: 7].astype(np.float32), vocal_peak=np.float64(np.max(np.abs(ref.vocal))),
+                        vad_segments=np.asarray([[s["start"], s["end"]] for s in ref.vad_segments], dtype=np.float64),
+                        cache_rms=np.asarray(ref.cache.rms_series, dtype=np.float32), beat_times=np.asarray(ref.cache.beat_times, dtype=np.float64))
+    print("wrote tests/golden/c2_full_oracle.npz")

@@ -340,3 +340,33 @@ def test_degenerate_tracks(hip_ctx, tmp_path):
         assert sum(hi - lo for lo, hi in r["segment_spans"]) == len(x)
     with pytest.raises(ValueError):
         sp.split_track(np.zeros(0, np.float32))
+
+
+def test_c2_full_size_track_against_oracle_fixture(hip_ctx, golden_dir):
+    """BASELINE configs[1] at full size (4-min C2 song): the GPU path against the CPU oracle's committed result
+    (tests/golden/make_c2_full.py; the oracle needs minutes per run) - every guard boundary, every manifest cut, the
+    segment labels, pause cut points, VAD segments and beat grid exact; stems and RMS series within 1e-4."""
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    g = np.load(golden_dir / "c2_full_oracle.npz")
+    mix = signals.c2_song(240.0, seed=2)
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=0), ctx=hip_ctx, max_items_per_forward=32)
+    backend.load_model()
+    sp = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend))
+    res = sp.split_track(mix)
+    assert res["sample_boundaries"] == g["sample_boundaries"].tolist()
+    assert res["cuts_samples"] == g["cuts"].tolist()
+    assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
+    assert [list(p) for p in res["segment_spans"]] == g["pieces"].tolist()
+    assert np.array_equal(np.asarray([p.cut_point for p in res["pauses"]]), g["pause_cut_points"])
+    assert np.array_equal(np.asarray([[s["start"], s["end"]] for s in res["vad_segments"]]), g["vad_segments"])
+    assert np.array_equal(np.asarray(res["feature_cache"].beat_times), g["beat_times"])
+    np.testing.assert_allclose(res["feature_cache"].rms_series, g["cache_rms"], rtol=SERIES_RTOL, atol=1e-7)
+    voc = res["vocal_track"]
+    peak = float(g["vocal_peak"])
+    assert float(np.max(np.abs(voc[: 4 * SR: 7] - g["vocal_head"]))) / peak < STEM_RTOL
+    nsec = len(mix) // SR
+    rms = np.sqrt(np.mean(voc[: nsec * SR].reshape(nsec, SR).astype(np.float64) ** 2, axis=1))
+    np.testing.assert_allclose(rms, g["vocal_rms_per_second"], rtol=1e-4, atol=1e-4 * peak)
