@@ -147,14 +147,21 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # Rehearsal switch for a ONE-GPU box only (never set by the driver): AC_BENCH_REHEARSAL=1 runs all ranks on cuda:0 with
+    # the gloo backend, so the N > 1 control flow (barriers, MAX over ranks, summary gather) can be exercised without N GPUs.
+    rehearsal = os.environ.get("AC_BENCH_REHEARSAL", "") == "1"
+    dev_index = 0 if rehearsal else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    device = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
+    device = f"cuda:{dev_index}"
+    torch.cuda.set_device(dev_index)
 
     from audio_cut_amd import _native, batch
     from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
@@ -206,7 +213,7 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     all_summaries = batch.gather_summaries(summaries)      # batch completion (RCCL barrier + all_gather_object)
