@@ -87,7 +87,7 @@ SIGNATURES = {
     "ac_lpc_formants": (C.c_int, [_P, _P, _I64, _I, _I, _I, C.c_float, _P, _P, _I64, _P]),
     "ac_zero_crossing_rate": (C.c_int, [_P, _P, _I64, _I, _I, _P, _I64, _P]),
     "ac_stft2048_spectral": (C.c_int, [_P, _P, _I64, _I, C.c_double, _P, _P, _I64, _P]),
-    "ac_segment_frame_rms": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
+    "ac_segment_frame_rms": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _I, _I, _I, _P, _I64, _P]),
     "ac_segment_sumsq_peak": (C.c_int, [_P, _P, _I64, _P, _P, _I, _P, _P, _P]),
     "ac_local_valley": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ac_resample_poly": (C.c_int, [_P, _P, _I64, _I, _I, _P, _I64, _I64, _P, _I64, _P]),
@@ -260,17 +260,18 @@ class Context:
         return out[: 3 * n].cpu().numpy()
 
     # -- post-path boundary policy ----------------------------------------------
-    def segment_frame_rms(self, x: torch.Tensor, seg_start: np.ndarray, seg_end: np.ndarray, frame: int, hop: int):
-        """librosa.feature.rms(y=x[a:b], frame, hop)[0] for every segment in one launch -> list of host float32 arrays."""
+    def segment_frame_rms(self, x: torch.Tensor, seg_start: np.ndarray, seg_end: np.ndarray, frame: int, hop: int, center: bool = True):
+        """Framed RMS of every segment in one launch -> list of host float32 arrays.  center=True:
+        librosa.feature.rms(y=x[a:b], frame, hop)[0]; center=False: windows from the segment start, the last zero padded."""
         self._chk_f32(x)
         a = np.asarray(seg_start, dtype=np.int64); b = np.asarray(seg_end, dtype=np.int64)
-        counts = 1 + (b - a) // hop
+        counts = (1 + (b - a) // hop) if center else -((a - b) // hop)
         off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
         nf = int(off[-1])
         out = torch.empty(nf, dtype=torch.float32, device=self.device)
         da, db_, do = self.to_device(a), self.to_device(b), self.to_device(off)
-        _check(self.lib.ac_segment_frame_rms(self._h, _ptr(x), x.numel(), _ptr(da), _ptr(db_), _ptr(do), len(a), frame, hop, _ptr(out), nf,
-                                             _stream()))
+        _check(self.lib.ac_segment_frame_rms(self._h, _ptr(x), x.numel(), _ptr(da), _ptr(db_), _ptr(do), len(a), frame, hop, int(center),
+                                             _ptr(out), nf, _stream()))
         host = out.cpu().numpy()
         return [host[off[i]: off[i + 1]] for i in range(len(a))]
 

@@ -48,4 +48,58 @@ def gather_summaries(local: List[Dict], group=None) -> List[Dict]:
     return sorted(merged, key=lambda d: d["track"])
 
 
-__all__ = ["assign_tracks", "summarize", "gather_summaries"]
+class TrackPipeline:
+    """Software pipeline over the tracks of ONE GPU: `depth` worker threads, each with its own HIP stream and its own
+    `SeamlessSplitter` (they share the read-only backend / U-Net weights).  While one track sits in its host-bound tail
+    (VAD bookkeeping, pause detection, guard, boundary policy: ~20 ms of small kernels and synchronisation round trips)
+    the next track's U-Net launches keep the GPU busy from the other stream; `separation_gate` keeps the U-Nets themselves
+    one after the other (two at once would only slow each other down).  Tracks stay independent: no state is shared
+    between workers, results come back in submission order."""
+
+    def __init__(self, splitters: Sequence, device) -> None:
+        import threading
+        import torch
+        self._device = torch.device(device)
+        self._workers = [(sp, torch.cuda.Stream(device=self._device)) for sp in splitters]
+        self.separation_gate = threading.Lock()      # one U-Net on the GPU at a time: pass it to split_track(separation_gate=...)
+
+    @property
+    def depth(self) -> int:
+        return len(self._workers)
+
+    def run(self, jobs: Sequence) -> List:
+        """`jobs[i](splitter)` -> result; every job runs under one worker's stream; returns the results in job order."""
+        import queue
+        import threading
+        import torch
+        todo: "queue.Queue" = queue.Queue()
+        for i, job in enumerate(jobs):
+            todo.put((i, job))
+        results: List = [None] * len(jobs)
+        errors: List[BaseException] = []
+
+        def work(splitter, stream) -> None:
+            with torch.cuda.device(self._device), torch.cuda.stream(stream):
+                while not errors:
+                    try:
+                        i, job = todo.get_nowait()
+                    except queue.Empty:
+                        break
+                    try:
+                        results[i] = job(splitter)
+                    except BaseException as exc:      # surfaced to the caller below; the other worker stops at its next job
+                        errors.append(exc)
+                        break
+                stream.synchronize()
+
+        threads = [threading.Thread(target=work, args=w, name=f"audiocut-track-{k}") for k, w in enumerate(self._workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results
+
+
+__all__ = ["assign_tracks", "summarize", "gather_summaries", "TrackPipeline"]

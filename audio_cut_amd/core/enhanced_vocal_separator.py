@@ -140,15 +140,18 @@ class EnhancedVocalSeparator:
 
     # ------------------------------------------------------------------------------------------
     def separate_for_detection(self, audio: np.ndarray, *, gpu_context: Optional[PipelineContext] = None,
-                               audio_dev: Optional[torch.Tensor] = None) -> SeparationResult:
-        """`audio_dev` (extension): the same mono track already resident in HBM; skips the upload."""
+                               audio_dev: Optional[torch.Tensor] = None, on_separation_done=None) -> SeparationResult:
+        """`audio_dev` (extension): the same mono track already resident in HBM; skips the upload.
+        `on_separation_done` (extension): called once the U-Net work of this track has left the GPU (the VAD results are
+        back), before the host-bound tail - `batch.TrackPipeline` uses it to let the next track's separation start."""
         backend = self._primary_backend
         if backend is None:
             raise RuntimeError("separator backend not initialised")
         start = time.time()
         ctx = self._ensure_pipeline_context(audio, gpu_context)
         try:
-            vocal, inst, cache, vad_segments, markers, confidence, state = self._separate_with_pipeline(audio, backend, ctx, audio_dev)
+            vocal, inst, cache, vad_segments, markers, confidence, state = self._separate_with_pipeline(
+                audio, backend, ctx, audio_dev, on_separation_done)
         except Exception as exc:
             ctx.mark_failure("separation", str(exc))
             raise
@@ -159,7 +162,7 @@ class EnhancedVocalSeparator:
             feature_cache=cache, vad_segments=vad_segments, gpu_meta=meta, pipeline_used=ctx.enabled, device_state=state)
 
     def _separate_with_pipeline(self, audio: np.ndarray, backend: IVocalSeparatorBackend, gpu_context: PipelineContext,
-                                audio_dev: Optional[torch.Tensor] = None):
+                                audio_dev: Optional[torch.Tensor] = None, on_separation_done=None):
         if not isinstance(backend, MDX23HipBackend):
             raise RuntimeError("only MDX23HipBackend drives the batched device path")
         sr = self.sample_rate
@@ -176,7 +179,7 @@ class EnhancedVocalSeparator:
             mix_dev = audio_dev
         else:
             mix_dev = hip.to_device(np.ascontiguousarray(audio, dtype=np.float32))
-        torch.cuda.synchronize(hip.device)
+        torch.cuda.current_stream(hip.device).synchronize()     # this stream only: another track may be in flight on the device
         h2d_ms = (time.perf_counter() - t0) * 1000.0
 
         mix_ready = torch.cuda.Event()
@@ -215,14 +218,18 @@ class EnhancedVocalSeparator:
         vad_fn = self._vad_inference_fn or EnergyGateVad(sr, hip)
         chunk_vad = SileroChunkVAD(sample_rate=sr, merge_gap_ms=float(get_config("advanced_vad.silero_merge_gap_ms", 120.0)),
                                    focus_pad_s=float(get_config("advanced_vad.focus_window_pad_s", 0.2)), inference_fn=vad_fn)
-        for plan, off, (cs, ce, es, ee) in zip(live_plans, sep.chunk_offsets, sep.chunk_ranges):
-            chunk_vocal = sep.chunk_vocal[off: off + (ce - cs)]
-            if isinstance(vad_fn, EnergyGateVad):
-                chunk_vad.process_chunk(plan, chunk_vocal, sr)
-            else:       # injected VadFn contract: host float32 chunk
-                chunk_vad.process_chunk(plan, chunk_vocal.cpu().numpy(), sr)
+        if isinstance(vad_fn, EnergyGateVad):     # every chunk's window RMS in one launch and one download
+            pre = vad_fn.batch_rms(sep.chunk_vocal, sep.chunk_offsets, [ce - cs for cs, ce, _, _ in sep.chunk_ranges])
+            for plan, chunk in zip(live_plans, pre):
+                chunk_vad.process_chunk(plan, chunk, sr)
+        else:                                     # injected VadFn contract: host float32 chunks
+            host = sep.chunk_vocal.cpu().numpy()
+            for plan, off, (cs, ce, es, ee) in zip(live_plans, sep.chunk_offsets, sep.chunk_ranges):
+                chunk_vad.process_chunk(plan, host[off: off + (ce - cs)], sr)
         vad_segments = chunk_vad.finalize()
         sep.finish()
+        if on_separation_done is not None:
+            on_separation_done()
 
         inst_energy = hip.mean_square(sep.instrumental) if sep.instrumental.numel() else 0.0
         has_inst = inst_energy > 0.0                                            # `:458` (`np.any(instrumental)`), reduced on the GPU

@@ -479,14 +479,15 @@ extern "C" int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_segment_frame_rms(const float* __restrict__ x, const int64_t* __restrict__ seg_start,
                                                            const int64_t* __restrict__ seg_end, const int64_t* __restrict__ frame_off,
-                                                           int n_seg, int frame, int hop, float* __restrict__ out, int64_t n_frames) {
+                                                           int n_seg, int frame, int hop, int center, float* __restrict__ out,
+                                                           int64_t n_frames) {
     const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= n_frames) return;
     const int lane = threadIdx.x & 63;
     int lo = 0, hi = n_seg - 1;                      // last segment with frame_off[s] <= f
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (frame_off[mid] <= f) lo = mid; else hi = mid - 1; }
     const int64_t a = seg_start[lo], b = seg_end[lo];
-    const int64_t c0 = a + (f - frame_off[lo]) * (int64_t)hop - frame / 2;
+    const int64_t c0 = a + (f - frame_off[lo]) * (int64_t)hop - (center ? frame / 2 : 0);
     double acc = 0.0;
     for (int i = lane; i < frame; i += 64) {
         const int64_t g = c0 + i;
@@ -497,12 +498,12 @@ __global__ __launch_bounds__(256) void k_segment_frame_rms(const float* __restri
 }
 
 extern "C" int ac_segment_frame_rms(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end,
-                                     const int64_t* frame_off, int n_seg, int frame, int hop, float* out, int64_t n_frames,
-                                     void* stream) {
+                                     const int64_t* frame_off, int n_seg, int frame, int hop, int center, float* out,
+                                     int64_t n_frames, void* stream) {
     AC_REQUIRE(ctx && x && seg_start && seg_end && frame_off && out, "null pointer");
     AC_REQUIRE(n > 0 && n_seg > 0 && frame > 0 && hop > 0 && n_frames > 0 && n_frames < (1LL << 33), "sizes must be positive");
     hipLaunchKernelGGL(k_segment_frame_rms, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, seg_start,
-                       seg_end, frame_off, n_seg, frame, hop, out, n_frames);
+                       seg_end, frame_off, n_seg, frame, hop, center, out, n_frames);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

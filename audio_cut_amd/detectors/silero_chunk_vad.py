@@ -76,6 +76,16 @@ def speech_timestamps(probs: np.ndarray, n_samples: int, win: int, sr: int, thre
     return spans
 
 
+class PrecomputedChunk:
+    """A chunk whose VAD window RMS values are already on the host (`EnergyGateVad.batch_rms`)."""
+
+    def __init__(self, rms: np.ndarray, n_samples: int) -> None:
+        self.rms, self.n = rms, int(n_samples)
+
+    def numel(self) -> int:
+        return self.n
+
+
 class EnergyGateVad:
     """Default `inference_fn`: per-window RMS on the GPU -> pseudo probability -> Silero hysteresis.
     Accepts a host chunk (the `VadFn` contract) or a device tensor (the separator's fast path)."""
@@ -86,8 +96,20 @@ class EnergyGateVad:
         self.floor_db, self.ceil_db = floor_db, ceil_db
         self._ctx = ctx
 
+    def batch_rms(self, packed_dev, offsets: Sequence[int], lengths: Sequence[int]) -> List["PrecomputedChunk"]:
+        """All chunks of a track in ONE launch and one download: `packed_dev` holds the chunks back to back."""
+        ctx = self._ctx or _native.Context()
+        self._ctx = ctx
+        a = np.asarray(offsets, dtype=np.int64)
+        b = a + np.asarray(lengths, dtype=np.int64)
+        rms = ctx.segment_frame_rms(packed_dev, a, b, self.win, self.win, center=False)
+        return [PrecomputedChunk(r, int(n)) for r, n in zip(rms, lengths)]
+
     def probs(self, chunk) -> Tuple[np.ndarray, int]:
         import torch
+        if isinstance(chunk, PrecomputedChunk):
+            db = 20.0 * np.log10(chunk.rms.astype(np.float64) + 1e-12)
+            return np.clip((db - self.floor_db) / (self.ceil_db - self.floor_db), 0.0, 1.0), chunk.n
         ctx = self._ctx or _native.Context()
         self._ctx = ctx
         x = chunk if isinstance(chunk, torch.Tensor) else ctx.to_device(np.asarray(chunk, dtype=np.float32))

@@ -256,12 +256,14 @@ int ac_stft2048_spectral(ac_ctx* ctx, const float* x, int64_t n, int hop, double
 
 /* ---- post-path boundary policy ------------------------------------------------------------ */
 
-/* `_classify_segments_vocal_presence` (core/seamless_splitter.py:2335-2342): librosa.feature.rms(y=segment, frame, hop) of
- * every segment [seg_start[s], seg_end[s]) in one launch; a frame sees zeros outside its own segment (centred, constant
- * padding).  frame_off[s] = index of segment s's first frame in `out` (frame_off[n_seg] = n_frames); segment s has
- * 1 + (seg_end - seg_start) / hop frames. */
+/* Framed RMS of every segment [seg_start[s], seg_end[s]) in one launch; a frame sees zeros outside its own segment.
+ * center = 1: librosa.feature.rms(y=segment, frame, hop) (centred frames, constant padding; segment s has
+ * 1 + len / hop frames) - `_classify_segments_vocal_presence` (core/seamless_splitter.py:2335-2342).
+ * center = 0: frames start at seg_start + j * hop (the last one zero padded; the caller picks the count) - the
+ * per-chunk VAD windows of detectors/silero_chunk_vad.py.  frame_off[s] = index of segment s's first frame in `out`. */
 int ac_segment_frame_rms(ac_ctx* ctx, const float* x, int64_t n, const int64_t* seg_start, const int64_t* seg_end,
-                         const int64_t* frame_off, int n_seg, int frame, int hop, float* out, int64_t n_frames, void* stream);
+                         const int64_t* frame_off, int n_seg, int frame, int hop, int center, float* out, int64_t n_frames,
+                         void* stream);
 /* `_refine_boundaries_local_valley` (core/seamless_splitter.py:2646-2661): for boundary c the window [c - radius, c + radius)
  * clipped to the signal, float64 'valid' moving mean of x^2 over `win`, dB = 20 log10(sqrt(mean + 1e-12) + 1e-12);
  * orig_db[k] = dB at clip(c - start - win/2), min_db / min_idx[k] = first minimum (index into the 'valid' series;
