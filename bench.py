@@ -85,10 +85,13 @@ def roofline_conv(probe, conv_ms: float, conv_flops: float, elapsed: float) -> d
                              "one launch per 3x3 conv of the U-Net)",
         "bound": "mfma", "achieved": round(achieved, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / F16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "f32_matrix_peak": F32_MATRIX_PEAK_TFLOPS, "frac_of_f32_matrix_peak": round(achieved / F32_MATRIX_PEAK_TFLOPS, 3),
         "mfma_issued_tflops": round(achieved * F16X3_ISSUE_FACTOR, 2),
         "frac_mfma_issued": round(achieved * F16X3_ISSUE_FACTOR / F16_MFMA_PEAK_TFLOPS, 4),
-        "note": "achieved/frac count algorithmic f32-conv FLOPs; the split issues 3.33x as many f16 MFMA FLOPs "
-                "(mfma_issued_tflops) to deliver f32-class products",
+        "note": "achieved/frac count algorithmic f32-conv FLOPs against the dense f16 MFMA peak the kernel runs on; the split issues "
+                "3.33x as many f16 MFMA FLOPs (mfma_issued_tflops) to deliver f32-class products, i.e. 2x the chip's f32 MFMA "
+                "peak (frac_of_f32_matrix_peak); an MFMA-only build of the same instruction stream tops out at ~1487 TFLOP/s "
+                "issued on random data (DESIGN.md 3.1)",
         "launches": len(probe), "avg_launch_ms": round(conv_ms / n, 4), "flops_per_launch": conv_flops / n,
         "share_of_step": round(conv_ms / 1e3 / max(1e-9, elapsed), 3),
     }
