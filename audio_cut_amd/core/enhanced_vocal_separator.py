@@ -140,10 +140,11 @@ class EnhancedVocalSeparator:
 
     # ------------------------------------------------------------------------------------------
     def separate_for_detection(self, audio: np.ndarray, *, gpu_context: Optional[PipelineContext] = None,
-                               audio_dev: Optional[torch.Tensor] = None, on_separation_done=None) -> SeparationResult:
+                               audio_dev: Optional[torch.Tensor] = None, separation_gate=None) -> SeparationResult:
         """`audio_dev` (extension): the same mono track already resident in HBM; skips the upload.
-        `on_separation_done` (extension): called once the U-Net work of this track has left the GPU (the VAD results are
-        back), before the host-bound tail - `batch.TrackPipeline` uses it to let the next track's separation start."""
+        `separation_gate` (extension, a lock shared by the workers of a `batch.TrackPipeline`): taken right before this
+        track's first separation kernel is queued (its index tables are already uploaded) and released once that work
+        has left the GPU (the VAD results are back), before the host-bound tail."""
         backend = self._primary_backend
         if backend is None:
             raise RuntimeError("separator backend not initialised")
@@ -151,7 +152,7 @@ class EnhancedVocalSeparator:
         ctx = self._ensure_pipeline_context(audio, gpu_context)
         try:
             vocal, inst, cache, vad_segments, markers, confidence, state = self._separate_with_pipeline(
-                audio, backend, ctx, audio_dev, on_separation_done)
+                audio, backend, ctx, audio_dev, separation_gate)
         except Exception as exc:
             ctx.mark_failure("separation", str(exc))
             raise
@@ -162,7 +163,7 @@ class EnhancedVocalSeparator:
             feature_cache=cache, vad_segments=vad_segments, gpu_meta=meta, pipeline_used=ctx.enabled, device_state=state)
 
     def _separate_with_pipeline(self, audio: np.ndarray, backend: IVocalSeparatorBackend, gpu_context: PipelineContext,
-                                audio_dev: Optional[torch.Tensor] = None, on_separation_done=None):
+                                audio_dev: Optional[torch.Tensor] = None, separation_gate=None):
         if not isinstance(backend, MDX23HipBackend):
             raise RuntimeError("only MDX23HipBackend drives the batched device path")
         sr = self.sample_rate
@@ -182,10 +183,30 @@ class EnhancedVocalSeparator:
         torch.cuda.current_stream(hip.device).synchronize()     # this stream only: another track may be in flight on the device
         h2d_ms = (time.perf_counter() - t0) * 1000.0
 
+        # 1. queue the whole separation (no host synchronisation inside)
+        gate_held = []
+
+        def take_gate() -> None:
+            if separation_gate is not None:
+                separation_gate.acquire()
+                gate_held.append(True)
+
+        def drop_gate() -> None:
+            if gate_held:
+                gate_held.pop()
+                separation_gate.release()
+        try:
+            return self._separate_gated(audio, backend, gpu_context, mix_dev, plans, timings, h2d_ms, take_gate, drop_gate)
+        finally:
+            drop_gate()
+
+    def _separate_gated(self, audio, backend, gpu_context, mix_dev, plans, timings, h2d_ms, take_gate, drop_gate):
+        sr = self.sample_rate
+        hip = backend.hip
+        total = len(audio)
         mix_ready = torch.cuda.Event()
         mix_ready.record()
-        # 1. queue the whole separation (no host synchronisation inside)
-        sep = backend.separate_track(mix_dev, sr, plans, timings, defer_sync=True)
+        sep = backend.separate_track(mix_dev, sr, plans, timings, defer_sync=True, before_launch=take_gate)
         sep_done = torch.cuda.Event()
         sep_done.record()
 
@@ -228,8 +249,7 @@ class EnhancedVocalSeparator:
                 chunk_vad.process_chunk(plan, host[off: off + (ce - cs)], sr)
         vad_segments = chunk_vad.finalize()
         sep.finish()
-        if on_separation_done is not None:
-            on_separation_done()
+        drop_gate()
 
         inst_energy = hip.mean_square(sep.instrumental) if sep.instrumental.numel() else 0.0
         has_inst = inst_energy > 0.0                                            # `:458` (`np.any(instrumental)`), reduced on the GPU

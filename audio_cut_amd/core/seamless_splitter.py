@@ -69,8 +69,8 @@ class SeamlessSplitter:
     # ------------------------------------------------------------------------------------------
     def split_track(self, original_audio: np.ndarray, mode: str = "v2.2_mdd", *, audio_dev=None, separation_gate=None) -> Dict:
         """Steps 2-9 of SURVEY.md §3.1 on an in-memory mono float32 track at `sample_rate`.
-        `separation_gate` (a lock shared by the workers of a `batch.TrackPipeline`): held while this track's U-Net occupies
-        the GPU, released before the host-bound tail so that the next track's separation start overlaps it.  (Queueing the
+        `separation_gate` (a lock shared by the workers of a `batch.TrackPipeline`): held from this track's first separation
+        kernel until its U-Net has left the GPU, released before the host-bound tail so that the next track overlaps it.  (Queueing the
         next U-Net behind a GPU-side event instead was measured slower: the tail's ~100 small kernels then wait behind
         1-2 ms U-Net kernels at every synchronisation round trip.)"""
         if mode not in self.SUPPORTED_MODES:
@@ -79,21 +79,8 @@ class SeamlessSplitter:
         if original_audio is None or len(original_audio) == 0:
             raise ValueError("split_track needs a non-empty mono track")
         t0 = time.perf_counter()
-        if separation_gate is None:
-            sep: SeparationResult = self.separator.separate_for_detection(original_audio, gpu_context=None, audio_dev=audio_dev)
-        else:
-            separation_gate.acquire()
-            released = []
-
-            def release_once() -> None:
-                if not released:
-                    released.append(True)
-                    separation_gate.release()
-            try:
-                sep = self.separator.separate_for_detection(original_audio, gpu_context=None, audio_dev=audio_dev,
-                                                            on_separation_done=release_once)
-            finally:
-                release_once()
+        sep: SeparationResult = self.separator.separate_for_detection(original_audio, gpu_context=None, audio_dev=audio_dev,
+                                                                     separation_gate=separation_gate)
         t_sep = time.perf_counter() - t0
         state = sep.device_state or {}
         vocal_track = sep.vocal_track

@@ -176,10 +176,12 @@ class MDX23HipBackend(IVocalSeparatorBackend):
 
     # -- batched fast path ------------------------------------------------------------------------
     def separate_track(self, track_dev: torch.Tensor, sr: int, plans: Sequence[ChunkPlan],
-                       timings: Optional[Dict[str, float]] = None, defer_sync: bool = False) -> TrackSeparation:
+                       timings: Optional[Dict[str, float]] = None, defer_sync: bool = False, before_launch=None) -> TrackSeparation:
         """All chunks of a resident track: STFT -> U-Net -> iSTFT -> stem assembly + OLA, no host bounce.
         Everything is queued on the current stream without a host synchronisation; `defer_sync=True` returns at once
-        (the caller overlaps host work and calls `result.finish()` later), otherwise the timings are read before returning."""
+        (the caller overlaps host work and calls `result.finish()` later), otherwise the timings are read before returning.
+        `before_launch` is called after the index tables are on the device and before the first kernel is queued
+        (`batch.TrackPipeline` waits there for the previous track's U-Net to leave the GPU)."""
         hip = self.hip
         net = self.net
         n = int(track_dev.numel())
@@ -210,6 +212,8 @@ class MDX23HipBackend(IVocalSeparatorBackend):
         d_offsets = hip.to_device(offsets[:-1])
         wave = torch.empty((n_items, 2, ITEM_LEN), dtype=torch.float32, device=hip.device)
         step = max(1, self.max_items_per_forward)
+        if before_launch is not None:
+            before_launch()
         events: List[List[torch.cuda.Event]] = []     # per sub-batch: [before stft, before net, before istft, after istft]
         for a in range(0, n_items, step):
             b = min(n_items, a + step)
