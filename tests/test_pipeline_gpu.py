@@ -370,3 +370,29 @@ def test_c2_full_size_track_against_oracle_fixture(hip_ctx, golden_dir):
     nsec = len(mix) // SR
     rms = np.sqrt(np.mean(voc[: nsec * SR].reshape(nsec, SR).astype(np.float64) ** 2, axis=1))
     np.testing.assert_allclose(rms, g["vocal_rms_per_second"], rtol=1e-4, atol=1e-4 * peak)
+
+
+def test_track_pipeline_matches_sequential_processing(hip_ctx):
+    """BASELINE config C3 in miniature: six different tracks through `batch.TrackPipeline` (two in flight, own streams,
+    shared U-Net weights) give, track by track, exactly what processing them one after the other gives."""
+    from audio_cut_amd import batch
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=0), ctx=hip_ctx, max_items_per_forward=16)
+    backend.load_model()
+    mk = lambda: SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend))
+    tracks = [signals.c2_song(d, seed=100 + i) for i, d in enumerate((24.0, 31.5, 18.2, 27.7, 12.3, 36.0))]
+    solo = mk()
+    ref = [solo.split_track(t) for t in tracks]
+    pipe = batch.TrackPipeline([mk(), mk()], hip_ctx.device)
+    got = pipe.run([(lambda sp, t=t: sp.split_track(t, separation_gate=pipe.separation_gate)) for t in tracks])
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert a["sample_boundaries"] == b["sample_boundaries"], i
+        assert a["cuts_samples"] == b["cuts_samples"] and a["segment_vocal_flags"] == b["segment_vocal_flags"], i
+        assert np.array_equal(a["vocal_track"], b["vocal_track"]), i          # same kernels, same order inside a track: bit-identical stems
+    summaries = [batch.summarize(i, r["sample_boundaries"], len(t) / SR) for i, (r, t) in enumerate(zip(got, tracks))]
+    assert [s["track"] for s in batch.gather_summaries(summaries)] == list(range(6))
+    with pytest.raises(ValueError):                                           # a failing job surfaces, the pipeline does not hang
+        pipe.run([lambda sp: sp.split_track(np.zeros(0, np.float32))])
