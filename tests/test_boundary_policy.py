@@ -102,3 +102,39 @@ def test_product_boundary_policy_on_gpu_matches_reference_fixture(hip_ctx, golde
     assert [int(f) for f in out["segment_vocal_flags"]] == g[f"policy{seed}_flags"].tolist()
     assert [list(p) for p in out["segment_spans"]] == g[f"policy{seed}_pieces"].tolist()
     assert int(out["segment_layout_applied"]) == int(g[f"policy{seed}_applied"][0])
+
+
+def test_layout_refiner_invariants_hold_on_random_inputs():
+    """Size-independent properties of the layout policy: the refined segments tile the original span without gaps, no
+    interior piece is shorter than min_gap (when a neighbour exists to absorb it), long segments are cut only where the
+    min-gap margins allow, and a second pass changes nothing once no segment is short or long (idempotence)."""
+    from audio_cut_amd.cutting import segment_layout_refiner as PL
+    rng = np.random.default_rng(7)
+    for case in range(200):
+        edges, kinds, rms, hop_s, beats, supp, cfg, midpoint = random_layout_case(rng, case)
+        conf = PL.LayoutConfig(**{**cfg, "beat_snap_ms": 0.0})
+        segs = [PL.Segment(float(edges[i]), float(edges[i + 1]), kinds[i]) for i in range(len(kinds))]
+        out = PL.refine_layout(segs, [], config=conf, sample_rate=SR, allow_midpoint_fallback=True).segments
+        assert out[0].start == segs[0].start and out[-1].end == segs[-1].end
+        assert all(out[i].end == out[i + 1].start for i in range(len(out) - 1))
+        assert all(s.end > s.start for s in out)
+        if len(out) > 1:
+            assert all(s.duration >= conf.min_gap_s - 1e-12 for s in out)
+        again = PL.refine_layout(out, [], config=conf, sample_rate=SR, allow_midpoint_fallback=True).segments
+        if all(conf.soft_min_s <= s.duration <= conf.soft_max_s for s in out):
+            assert [(s.start, s.end, s.kind) for s in again] == [(s.start, s.end, s.kind) for s in out]
+    off = PL.refine_layout(segs, [], config=PL.LayoutConfig(enable=False), sample_rate=SR).segments
+    assert [(s.start, s.end) for s in off] == [(s.start, s.end) for s in segs]
+
+
+def test_sample_level_split_tiles_the_track():
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n = int(rng.integers(1, 400000))
+        k = int(rng.integers(0, 12))
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=k)]))
+        flags = [bool(b) for b in rng.integers(0, 2, size=len(cuts) - 1)]
+        pieces, merged = OL.split_at_sample_level(n, cuts, flags, SR)
+        assert pieces[0][0] == 0 and pieces[-1][1] == n and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        assert len(merged) == len(pieces) and (any(flags) == any(merged))
+        assert all(hi - lo >= min(n, int(0.01 * SR)) for lo, hi in pieces) or len(pieces) == 1
