@@ -77,6 +77,7 @@ SIGNATURES = {
     "ac_space_to_depth2x": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_depth_to_space2x_bias_relu_mul": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
+    "ac_conv3x3_f16x3_first": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P]),
     "ac_conv1x1_small": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I64, _I, _P]),
     "ac_down2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P]),
@@ -141,6 +142,8 @@ class Context:
         self.conv_impl = os.environ.get("AUDIOCUT_CONV_IMPL", "f16x3")
         # TDF layers: "f16x3" = ac_tdf_linear_f16x3 (fused GEMM + affine + ReLU (+ residual)), "rocblas" = float32 rocBLAS + epilogues
         self.tdf_impl = os.environ.get("AUDIOCUT_TDF_IMPL", "f16x3")
+        # the graph's first 1x1 conv is generated inside the first 3x3 conv's loader (ac_conv3x3_f16x3_first) unless disabled
+        self.fuse_first_conv = os.environ.get("AUDIOCUT_FUSE_FIRST_CONV", "1") != "0"
         # 2x2 resampling layers: "f16x3" = ac_down2x_f16x3 / ac_up2x_f16x3 (one fused MFMA kernel each),
         # "gemm" = gather/scatter kernels around a rocBLAS float32 GEMM, "miopen" = strided / transposed convolutions
         self.resample_impl = os.environ.get("AUDIOCUT_RESAMPLE_IMPL", "f16x3")
@@ -556,6 +559,20 @@ class Context:
             out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
         _check(self.lib.ac_conv3x3_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
                                          float(w_unscale), int(relu), _stream()))
+        return out
+
+    def conv3x3_f16x3_first(self, spec: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
+                            c_out: int, w_unscale: float, relu: bool = True) -> torch.Tensor:
+        """relu(conv3x3(relu(conv1x1(spec, w1) + b1))) in one kernel: the 1x1 convolution's output never touches HBM."""
+        if spec.dtype != torch.float32 or spec.dim() != 4 or not spec.is_contiguous():
+            raise NativeError("conv3x3_f16x3_first expects a contiguous float32 NCHW tensor")
+        b, c0, h, w = spec.shape
+        w1 = w1.reshape(w1.shape[0], -1)
+        if w1.shape[1] != c0 or not w1.is_contiguous():
+            raise NativeError("conv3x3_f16x3_first: w1 must be [C_in, C0(,1,1)] contiguous")
+        out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_conv3x3_f16x3_first(self._h, _ptr(spec), _ptr(w1), _ptr(b1), _ptr(w_packed), _ptr(bias), _ptr(out), b, c0,
+                                               w1.shape[0], c_out, h, w, float(w_unscale), int(relu), _stream()))
         return out
 
     def tdf_linear_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, n_out: int, scale: torch.Tensor, shift: torch.Tensor,

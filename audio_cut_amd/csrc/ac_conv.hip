@@ -47,10 +47,15 @@ __device__ inline int cv_phys(int c) { return c ^ (((c >> 2) & 1) << 1); } // st
 #define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
 #define CV_OUT_STRIDE (CV_TW + 4)                                          // floats per (co, row) line of the output staging
 
-template <bool RELU>
+// FIRST = true fuses the graph's first 1x1 convolution (C0 <= 8 spectrogram channels -> C_in, + bias + ReLU) into the
+// loader: x is the [B][C0][H][W] spectrogram, the C_in-channel tensor the 3x3 conv consumes is generated per staged
+// pixel (w1 [C_in][C0], b1 [C_in]; float32 FMAs in ac_conv1x1_small's order, so the values are bit-identical to running
+// that kernel first) and never touches HBM.
+template <bool RELU, bool FIRST>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int C_in, int C_out, int H, int W, float w_unscale, int bw) {
+                                                          int C_in, int C_out, int H, int W, float w_unscale, int bw,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1, int C0) {
     // one LDS arena: [hi patch | lo patch | weight fragments] during the K loop, re-used as the output staging tile
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * CV_PH * CV_LW * CV_PIX_STRIDE * 2 + CV_WFRAGS * 16];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     const int y0 = (t / bw) * CV_TH, x0 = (band * bw + t % bw) * CV_TW;
     const int n_cb = C_in / CV_CB;
     const size_t plane = (size_t)H * W;
-    const float* xb = x + (size_t)b * C_in * plane;
+    const float* xb = x + (size_t)b * (FIRST ? C0 : C_in) * plane;
 
     f32x4 acc[CV_MT][4];
 #pragma unroll
@@ -110,6 +115,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     }
     float4 pre_x[CV_ACT_ITERS][4];
     f16x8 pre_w[CV_W_ITERS];
+    __shared__ float s_first[FIRST ? 5 * 64 : 1];        // FIRST: [channel][w1[0..3], b1] of the fused 1x1 conv (C_in <= 64)
+    if (FIRST) {
+        for (int c = tid; c < C_in; c += 256) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_first[c * 5 + j] = (j < C0) ? w1[c * C0 + j] : 0.f;
+            s_first[c * 5 + 4] = b1[c];
+        }
+    }
 
     auto prefetch = [&](int cb) {
         const f16x8* wcb = wbase + (size_t)cb * CV_WFRAGS;
@@ -122,9 +135,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ci = cb * CV_CB + (a_c4[i] < 0 ? 0 : a_c4[i]) * 4 + q;
-                pre_x[i][q] = (a_src[i] >= 0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_src[i])
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int ci = FIRST ? q : cb * CV_CB + (a_c4[i] < 0 ? 0 : a_c4[i]) * 4 + q;      // FIRST: the spectrogram's channels
+                pre_x[i][q] = (a_src[i] >= 0 && (!FIRST || q < C0)) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_src[i])
+                                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -141,12 +154,29 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
             if (a_c4[i] < 0) continue;
             const float* v4[4] = {&pre_x[i][0].x, &pre_x[i][1].x, &pre_x[i][2].x, &pre_x[i][3].x};
+            float gen[4][4];                                           // FIRST: [virtual channel q][pixel k]
+            if (FIRST) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cb * CV_CB + a_c4[i] * 4 + q;
+                    const float wv[4] = {s_first[c * 5], s_first[c * 5 + 1], s_first[c * 5 + 2], s_first[c * 5 + 3]};
+                    const float bv = s_first[c * 5 + 4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float a = bv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < C0) a = fmaf(wv[j], v4[j][k], a);
+                        gen[q][k] = (a_src[i] >= 0) ? fmaxf(a, 0.f) : 0.f;       // zero padding applies to the conv input, not to relu(b1)
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                              // 4 pixels of the float4
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fminf(fmaxf(v4[q][k], -65504.f), 65504.f);
+                    const float v = fminf(fmaxf(FIRST ? gen[q][k] : v4[q][k], -65504.f), 65504.f);
                     const _Float16 hv = (_Float16)v;                   // v_cvt_f16_f32, round to nearest even
                     h4[q] = f16_bits(hv);
                     l4[q] = f16_bits((_Float16)(v - (float)hv));
@@ -211,8 +241,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     }
 }
 
-extern "C" int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                                 int C_out, int H, int W, float w_unscale, int relu, void* stream) {
+static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
+                     int H, int W, float w_unscale, int relu, void* stream, const float* w1, const float* b1, int C0) {
     AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
     AC_REQUIRE(B > 0 && C_in > 0 && C_in % CV_CB == 0 && C_out > 0 && C_out % CV_COB == 0, "C_in % 16 == 0 and C_out % 48 == 0");
     AC_REQUIRE(H > 0 && H % CV_TH == 0 && W > 0 && W % CV_TW == 0, "H % 8 == 0 and W % 32 == 0");
@@ -222,10 +252,28 @@ extern "C" int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packe
     const int tiles_x = W / CV_TW;
     const int bw = tiles_x % 4 == 0 ? 4 : (tiles_x % 3 == 0 ? 3 : (tiles_x % 2 == 0 ? 2 : 1));   // column-band width (tiles)
     dim3 grid((unsigned)nblk), block(256);
-    if (relu)
-        hipLaunchKernelGGL(k_conv3x3_f16x3<true>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw);
-    else
-        hipLaunchKernelGGL(k_conv3x3_f16x3<false>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw);
+    hipStream_t st = (hipStream_t)stream;
+    const f16x8* wp = (const f16x8*)w_packed;
+    if (w1) {
+        AC_REQUIRE(b1 && C0 >= 1 && C0 <= 4 && C_in <= 64, "fused first conv: 1 <= C0 <= 4, C_in <= 64");
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0);
+    } else {
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0);
+    }
     AC_LAUNCH_CHECK();
     return AC_OK;
+}
+
+extern "C" int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                                 int C_out, int H, int W, float w_unscale, int relu, void* stream) {
+    return cv_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, nullptr, nullptr, 0);
+}
+
+extern "C" int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,
+                                       const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W,
+                                       float w_unscale, int relu, void* stream) {
+    AC_REQUIRE(w1 && b1, "null pointer");
+    return cv_launch(ctx, spec, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, w1, b1, C0);
 }

@@ -302,10 +302,22 @@ class _Block(nn.Module):
             return hip.tdf_linear_f16x3(y, self.lwp1, self.lw1.shape[0], self.ls1.view(-1), self.lb1.view(-1), self._l_unscale[1], resid=x)
         return hip.affine_relu_add(F.linear(y, self.lw1), self.ls1.view(-1), self.lb1.view(-1), x)
 
-    def forward(self, x: torch.Tensor, hip=None, probe=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, hip=None, probe=None, first=None) -> torch.Tensor:
         if hip is not None:
-            # dense contractions in MIOpen / rocBLAS, every elementwise hop as ONE fused HIP pass (ac_epilogue.hip)
-            for j in range(self.l):
+            # `first` = (w1, b1) of the graph's first 1x1 convolution: fused into this block's first 3x3 conv (x is the spectrogram)
+            start = 0
+            if first is not None:
+                if probe is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                spec = x
+                x = hip.conv3x3_f16x3_first(spec, first[0], first[1], self.cwp0, self.cb0, self.cw0.shape[0], self._w_unscale[0], relu=True)
+                if probe is not None:
+                    e1.record()
+                    c = self.cw0.shape[0]
+                    probe.append((e0, e1, 2.0 * spec.shape[0] * c * c * 9 * spec.shape[2] * spec.shape[3]))
+                start = 1
+            for j in range(start, self.l):
                 x = self._conv(x, j, hip, probe)
             return self._tdf(x, hip)
         for j in range(self.l):
@@ -402,10 +414,18 @@ class TfcTdfNet(nn.Module):
         skips: List[torch.Tensor] = []
         if hip is not None:
             ends_hip = (spec_tf.shape[2] * spec_tf.shape[3]) % 4 == 0 and spec_tf.is_contiguous()
-            x = hip.conv1x1_small(spec_tf, self.first_w, self.first_b, relu=True) if ends_hip \
-                else hip.bias_relu_(F.conv2d(spec_tf, self.first_w, None), self.first_b)
+            fuse_first = (ends_hip and getattr(hip, "conv_impl", "f16x3") == "f16x3" and getattr(hip, "fuse_first_conv", True)
+                          and hasattr(self.enc[0], "cwp0") and self.first_w.shape[0] <= 64 and spec_tf.shape[1] <= 4 and spec_tf.shape[2] % 8 == 0 and spec_tf.shape[3] % 32 == 0)
+            if fuse_first:
+                x = spec_tf
+            else:
+                x = hip.conv1x1_small(spec_tf, self.first_w, self.first_b, relu=True) if ends_hip \
+                    else hip.bias_relu_(F.conv2d(spec_tf, self.first_w, None), self.first_b)
             for i in range(n):
-                x = self.enc[i](x, hip, self.conv_probe)
+                if i == 0 and fuse_first:
+                    x = self.enc[0](x, hip, self.conv_probe, first=(self.first_w, self.first_b))
+                else:
+                    x = self.enc[i](x, hip, self.conv_probe)
                 skips.append(x)
                 x = self._down(x, i, hip)
             x = self.bottleneck(x, hip, self.conv_probe)

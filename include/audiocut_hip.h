@@ -290,6 +290,13 @@ int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, c
  * vocal_smart_splitter/utils/audio_export.py:109-111.  out [3 * n] bytes. */
 int ac_pack_pcm24(ac_ctx* ctx, const float* x, int64_t n, unsigned char* out, void* stream);
 
+/* ac_conv3x3_f16x3 with the graph's first 1x1 convolution (spec [B][C0][H][W], C0 <= 4, w1 [C_in][C0], b1 [C_in], + ReLU;
+ * the first Conv + BatchNormalization + Relu nodes at separation/backends.py:358) fused into its loader: the C_in-channel
+ * tensor is generated per staged pixel with ac_conv1x1_small's arithmetic (bit-identical) and never written to HBM. */
+int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,
+                           const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W, float w_unscale,
+                           int relu, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score

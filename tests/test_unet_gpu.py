@@ -203,3 +203,31 @@ def test_conv1x1_small_kernel(hip_ctx):
         ref = F.conv2d(x.double(), wt.double(), b.double())
         ref = F.relu(ref) if relu else ref
         assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6, (ci, co)
+
+
+def test_first_conv_fused_into_the_3x3_loader_is_bit_identical(hip_ctx):
+    """ac_conv3x3_f16x3_first == ac_conv1x1_small followed by ac_conv3x3_f16x3, bit for bit (same float32 FMA order for the
+    generated channels, same zero padding of the conv input), and the whole net is unchanged by the fusion."""
+    from audio_cut_amd.separation.conv_pack import pack_conv3x3
+    g = torch.Generator().manual_seed(8)
+    dev = hip_ctx.device
+    spec = (torch.randn(2, 4, 16, 64, generator=g) * 3).to(dev)
+    w1 = (torch.randn(48, 4, 1, 1, generator=g) * 0.5).to(dev); b1 = (torch.randn(48, generator=g) * 0.3).to(dev)
+    w3 = torch.randn(48, 48, 3, 3, generator=g) / np.sqrt(9 * 48); b3 = (torch.randn(48, generator=g) * 0.1).to(dev)
+    packed, un = pack_conv3x3(w3.numpy())
+    wp = torch.from_numpy(packed.view(np.int16)).to(dev)
+    mid = hip_ctx.conv1x1_small(spec, w1, b1, relu=True)
+    ref = hip_ctx.conv3x3_f16x3(mid, wp, b3, 48, un, relu=True)
+    got = hip_ctx.conv3x3_f16x3_first(spec, w1, b1, wp, b3, 48, un, relu=True)
+    assert torch.equal(got, ref)
+    spec_net = TfcTdfSpec()
+    w = synth_weights(spec_net, seed=0)
+    net = TfcTdfNet(w, spec_net, hip=hip_ctx).to(dev).eval()
+    x = (torch.randn(1, 4, 32, 3072, generator=g) * 2.0).to(dev)
+    a = net.forward_tf(x)
+    hip_ctx.fuse_first_conv = False
+    try:
+        b = net.forward_tf(x)
+    finally:
+        hip_ctx.fuse_first_conv = True
+    assert torch.equal(a, b)
