@@ -1,14 +1,25 @@
 """Known answers the reference's own unit tests hold for the boundary-policy row, replayed against
-the product's host logic and, where the case needs no ASR prior, against the oracle.  The cases are the reference's
-inputs and expected outputs (`tests/unit/test_segment_layout_refiner.py`,
-`tests/unit/test_cpu_baseline_perfect_reconstruction.py`); they are data, rebuilt here from their description.
+the product's host logic and, where the case needs no ASR prior, against the oracle, followed by the reference's cases
+for the VPBD pool (§8 a18).  The cases are the reference's inputs and expected outputs
+(`tests/unit/test_segment_layout_refiner.py`, `tests/unit/test_cpu_baseline_perfect_reconstruction.py`, and the files
+named at the second block); they are data, rebuilt here from their description.  CPU only.
 """
+import json
+from types import SimpleNamespace as NS
 from typing import List
 
 import numpy as np
 
+from audio_cut_amd.analysis.boundary_features import BoundaryFeatureExtractor, BoundaryFeatures, LyricsTimeline
 from audio_cut_amd.analysis.features_cache import TrackFeatureCache
+from audio_cut_amd.config import reset_runtime_config, set_runtime_config
 from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+from audio_cut_amd.core.vocal_phrase_boundary_detector import VocalPhraseBoundaryDetector
+from audio_cut_amd.cutting.cut_candidate import CandidateSource, CutCandidate, adapt_legacy_acoustic_candidates
+from audio_cut_amd.cutting.global_cut_planner import (GlobalCutPlanner, GlobalCutPlannerConfig, apply_guard_shift_metadata,
+                                                      planner_result_to_cut_points)
+from audio_cut_amd.cutting.phrase_boundary_scorer import PhraseBoundaryScorer, write_candidate_debug_json
+from audio_cut_amd.cutting.refine import CutAdjustment
 from audio_cut_amd.cutting.segment_layout_refiner import LayoutConfig, Segment, refine_layout
 from oracle import layout as OL
 
@@ -101,3 +112,124 @@ def test_sample_level_split_reconstructs_the_track_exactly():
     assert np.array_equal(np.concatenate(pieces), audio)
     spans, oflags = OL.split_at_sample_level(len(audio), cuts, flags, 1000)
     assert oflags == flags and spans == list(zip(cuts[:-1], cuts[1:]))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# VPBD pool row: the reference's unit-test cases for the planner, the scorer, the candidate / feature
+# containers and the feature extractor (`tests/unit/test_global_cut_planner.py`, `test_phrase_boundary_scorer.py`,
+# `test_boundary_data_models.py`, `test_boundary_features.py`, `test_boundary_features_tolerance.py`,
+# `test_vocal_phrase_boundary_detector.py:22-49`).  Words / sentences / voiced regions are duck-typed records here: the
+# lyrics providers that would produce them are out of scope, the arithmetic over them is not.
+# ----------------------------------------------------------------------------------------------------------------------
+
+def test_planner_dynamic_path_honours_duration_limits():
+    plan = GlobalCutPlanner(GlobalCutPlannerConfig(hard_min_s=3.0, hard_max_s=8.0, target_min_s=4.0, target_max_s=7.0)).plan(
+        [CutCandidate(4.0, 0.8, CandidateSource.LYRICS_GAP), CutCandidate(10.0, 0.9, CandidateSource.SENTENCE_END),
+         CutCandidate(16.0, 0.7, CandidateSource.ACOUSTIC_PAUSE)], duration_s=20.0)
+    assert plan.feasible is True and plan.cut_times == [0.0, 4.0, 10.0, 16.0, 20.0]
+    assert [c.t for c in plan.selected_candidates] == [4.0, 10.0, 16.0]
+    assert plan.metadata["planner"] == "dynamic_programming"
+
+
+def test_planner_keeps_the_best_candidate_per_second():
+    plan = GlobalCutPlanner(GlobalCutPlannerConfig(hard_min_s=2.0, hard_max_s=8.0, max_candidates_per_second=1.0)).plan(
+        [CutCandidate(5.10, 0.1, CandidateSource.LYRICS_GAP), CutCandidate(5.20, 0.9, CandidateSource.LYRICS_GAP),
+         CutCandidate(5.30, 0.8, CandidateSource.LYRICS_GAP)], duration_s=10.0)
+    assert [c.t for c in plan.selected_candidates] == [5.2]
+    assert sorted(c.t for c in plan.suppressed_candidates) == [5.1, 5.3]
+
+
+def test_planner_charges_vocal_risk_and_beat_conflict():
+    plan = GlobalCutPlanner(GlobalCutPlannerConfig(hard_min_s=4.0, hard_max_s=9.0, vocal_risk_weight=0.5, beat_conflict_weight=0.4)).plan(
+        [CutCandidate(6.0, 0.9, CandidateSource.ACOUSTIC_PAUSE, features={"vocal_cut_risk": 1.0}),
+         CutCandidate(7.0, 0.8, CandidateSource.LYRICS_GAP, features={"beat_conflict": 0.0})], duration_s=14.0)
+    assert plan.cut_times == [0.0, 7.0, 14.0]
+
+
+def test_planner_rescue_grid_when_no_path_exists():
+    plan = GlobalCutPlanner(GlobalCutPlannerConfig(hard_min_s=3.0, hard_max_s=8.0, rescue_enabled=True)).plan([], duration_s=21.0)
+    assert plan.feasible is True and plan.cut_times == [0.0, 7.0, 14.0, 21.0] and plan.metadata["planner"] == "rescue"
+
+
+def test_planner_result_to_cut_points_and_guard_shift_metadata():
+    plan = GlobalCutPlanner(GlobalCutPlannerConfig(hard_min_s=2.0, hard_max_s=8.0)).plan(
+        [CutCandidate(4.0, 0.8, CandidateSource.LYRICS_GAP)], duration_s=8.0)
+    pts = planner_result_to_cut_points(plan)
+    updated = apply_guard_shift_metadata(plan, [CutAdjustment(raw_time=4.0, guard_time=4.1, final_time=4.1, score=0.8,
+                                                              guard_shift_ms=100.0, final_shift_ms=100.0)])
+    assert [(p.t, p.score, p.kind) for p in pts] == [(4.0, 0.8, "lyrics_gap")]
+    assert updated.metadata["guard_shift_ms_by_raw_time"][4.0] == 100.0
+
+
+def test_scorer_clamps_reads_config_and_annotates(tmp_path):
+    scorer = PhraseBoundaryScorer(weights={"acoustic_pause": 0.5, "asr_gap": 0.4, "sentence_end": 0.3, "inside_word_penalty": 1.0,
+                                           "singing_penalty": 1.0})
+    assert scorer.score(BoundaryFeatures(acoustic_pause=1.0, asr_gap=1.0, sentence_end=1.0)) == 1.0
+    assert scorer.score(BoundaryFeatures(acoustic_pause=1.0, inside_word_penalty=1.0, singing_penalty=1.0)) == 0.0
+    cfg = PhraseBoundaryScorer.from_config({"weights": {"asr_gap": 0.25, "inside_word_penalty": 0.5}})
+    assert cfg.weights["asr_gap"] == 0.25 and cfg.weights["inside_word_penalty"] == 0.5
+    assert PhraseBoundaryScorer(weights={"breath": 0.2}).score(BoundaryFeatures(breath=1.0)) == 0.2
+    feats = BoundaryFeatures(asr_gap=1.0, sentence_end=1.0)
+    scored = PhraseBoundaryScorer(weights={"asr_gap": 0.5, "sentence_end": 0.5}).score_candidate(
+        CutCandidate(1.2, 0.0, CandidateSource.LYRICS_GAP), feats)
+    assert scored.score == 1.0 and scored.features == feats.to_dict() and "vpbd_score" in scored.reasons
+    path = tmp_path / "candidates.json"
+    write_candidate_debug_json([CutCandidate(1.2, 0.8, CandidateSource.LYRICS_GAP, reasons=["asr_gap"], features={"asr_gap": 1.0})], path)
+    payload = json.loads(path.read_text(encoding="utf-8"))
+    assert payload["candidates"][0]["source"] == "lyrics_gap" and payload["candidates"][0]["features"]["asr_gap"] == 1.0
+
+
+def test_candidate_and_feature_containers_clamp():
+    c = CutCandidate(t=1.25, score=1.5, source="lyrics_gap", reasons=["word gap"], features={"asr_gap": 0.9}, meta={"word_left": "hello"})
+    assert c.score == 1.0 and c.source == CandidateSource.LYRICS_GAP and c.to_dict()["source"] == "lyrics_gap"
+    f = BoundaryFeatures(acoustic_pause=2.0, asr_gap=-1.0, sentence_end=0.5)
+    assert f.acoustic_pause == 1.0 and f.asr_gap == 0.0 and f.to_dict()["sentence_end"] == 0.5
+    adapted = adapt_legacy_acoustic_candidates([(1.25, 0.7, {"rms_valley_db": -45.0})], source=CandidateSource.ACOUSTIC_PAUSE)
+    assert adapted[0].source == CandidateSource.ACOUSTIC_PAUSE and adapted[0].score == 0.7
+    assert adapted[0].meta["rms_valley_db"] == -45.0 and "legacy_acoustic" in adapted[0].reasons
+
+
+def _word(text, a, b, confidence=None):
+    return NS(text=text, start_s=a, end_s=b, confidence=confidence)
+
+
+def _sung_timeline() -> LyricsTimeline:
+    return LyricsTimeline(
+        words=[_word("hello", 0.50, 0.90, 0.95), _word("world", 1.40, 1.80, 0.94), _word("again", 3.00, 3.50, 0.40)],
+        sentences=[_word("hello world!", 0.50, 1.80, 0.90)],
+        vad_regions=[NS(start_s=0.45, end_s=1.90, confidence=0.92, kind="singing"), NS(start_s=2.80, end_s=3.70, confidence=0.40, kind="singing")],
+        duration_s=5.0, source="fake")
+
+
+def test_feature_extractor_word_singing_and_gap_terms():
+    ex = BoundaryFeatureExtractor(timeline=_sung_timeline(), beat_times=[1.0, 2.0], mdd_times=[1.6])
+    inside, low_conf, gap = ex.extract(0.70), ex.extract(3.20), ex.extract(1.15)
+    assert inside.inside_word_penalty == 1.0 and inside.singing_penalty == 1.0
+    assert 0.0 < low_conf.inside_word_penalty < 1.0 and 0.0 < low_conf.singing_penalty < 1.0
+    assert gap.asr_gap > 0.0
+    f = BoundaryFeatureExtractor(timeline=_sung_timeline(), beat_times=[1.80], mdd_times=[1.78], affinity_tolerance_s=0.05).extract(1.80)
+    assert f.sentence_end > 0.0 and f.beat_affinity == 1.0 and f.mdd_affinity > 0.0
+
+
+def test_feature_extractor_tolerances_and_risk_terms():
+    line = LyricsTimeline(words=[_word("line", 1.0, 2.0, 0.95)], sentences=[_word("line.", 1.0, 2.0, 1.0)], duration_s=4.0, source="fake")
+    assert BoundaryFeatureExtractor(timeline=line).extract(1.85).sentence_end > 0.0
+    ex = BoundaryFeatureExtractor(timeline=line, word_edge_tolerance_ms=60.0)
+    centre, edge = ex.extract(1.50), ex.extract(1.98)
+    assert centre.inside_word_penalty == 1.0 and 0.0 < edge.inside_word_penalty < centre.inside_word_penalty
+    rms = np.full(100, 0.1, dtype=np.float32); rms[39:43] = 1.0
+    ex = BoundaryFeatureExtractor(timeline=LyricsTimeline(duration_s=5.0, source="none"), rms_series=rms, hop_s=0.05)
+    assert ex.extract(0.25).vocal_cut_risk < 0.2 and ex.extract(2.0).vocal_cut_risk > 0.8
+    ex = BoundaryFeatureExtractor(timeline=LyricsTimeline(duration_s=5.0, source="none"), beat_times=[1.0, 2.0], affinity_tolerance_s=0.12)
+    assert ex.extract(1.0).beat_conflict == 0.0 and ex.extract(1.35).beat_conflict > 0.8
+
+
+def test_zero_beat_base_score_switches_beat_candidates_off():
+    set_runtime_config({"vpbd.beat_candidates.enable": True, "vpbd.beat_candidates.bars_per_cut": 2, "vpbd.beat_candidates.base_score": 0.0})
+    try:
+        cache = NS(beat_times=np.arange(0.0, 8.001, 0.5, dtype=np.float32), rms_series=np.full(160, 0.8, dtype=np.float32), hop_s=0.05)
+        got = VocalPhraseBoundaryDetector(sample_rate=16000)._build_beat_candidates(
+            vocal_track=np.full(16000 * 8, 0.2, dtype=np.float32), feature_cache=cache, duration_s=8.0)
+    finally:
+        reset_runtime_config()
+    assert got == []
