@@ -100,30 +100,62 @@ class ExportResult:
 
 
 class SegmentExporter:
-    """`segment_exporter.py:25-110`: `segment_{index:03d}_{human|music}{suffix}_{duration:.1f}.wav`."""
+    """`segment_exporter.py:25-110`: `segment_{index:03d}_{human|music}[_lib]{suffix}[_{duration:.1f}].{ext}`.
+
+    `export_segments` / `export_full_track` keep the reference's array-in signatures; `export_spans` is the form the
+    device path uses (one PackedTrack converted on the GPU, every piece a byte range of it)."""
 
     def __init__(self, sample_rate: int = 44100) -> None:
         self.sample_rate = sample_rate
 
+    @staticmethod
+    def _stem(i: int, n_samples: int, sample_rate: int, *, segment_is_vocal, lib_flags, lib_suffix: str, file_suffix: str,
+              duration_map, index_offset: int, always_append_duration: bool) -> str:
+        label = "human" if (bool(segment_is_vocal[i]) if i < len(segment_is_vocal) else True) else "music"
+        lib = lib_suffix if (lib_flags is not None and i < len(lib_flags) and bool(lib_flags[i])) else ""
+        seconds: Optional[float] = None
+        if duration_map is not None and i in duration_map:
+            seconds = max(0.0, float(duration_map[i]))
+        elif always_append_duration:
+            seconds = n_samples / float(sample_rate)
+        tail = file_suffix if seconds is None else f"{file_suffix}_{seconds:.1f}"
+        return f"segment_{i + index_offset:03d}_{label}{lib}{tail}"
+
+    def export_segments(self, segments: Sequence[np.ndarray], output_dir: str, *, segment_is_vocal: Sequence[bool], export_format: str,
+                        export_options: Optional[Dict[str, object]], lib_flags: Optional[Sequence[bool]] = None, lib_suffix: str = "_lib",
+                        subdir: Optional[str] = None, file_suffix: str = "", duration_map: Optional[Dict[int, float]] = None,
+                        index_offset: int = 1, always_append_duration: bool = False) -> List[str]:
+        base = Path(output_dir) / subdir if subdir else Path(output_dir)
+        base.mkdir(parents=True, exist_ok=True)
+        saved: List[str] = []
+        for i, piece in enumerate(segments):
+            stem = self._stem(i, len(piece), self.sample_rate, segment_is_vocal=segment_is_vocal, lib_flags=lib_flags,
+                              lib_suffix=lib_suffix, file_suffix=file_suffix, duration_map=duration_map, index_offset=index_offset,
+                              always_append_duration=always_append_duration)
+            saved.append(str(export_audio(piece, self.sample_rate, base / stem, export_format, options=export_options)))
+        return saved
+
     def export_spans(self, track: PackedTrack, spans: Sequence[Tuple[int, int]], output_dir: str, *, segment_is_vocal: Sequence[bool],
-                     subdir: Optional[str] = None, file_suffix: str = "", duration_map: Optional[Dict[int, float]] = None,
-                     index_offset: int = 1) -> List[str]:
+                     lib_flags: Optional[Sequence[bool]] = None, lib_suffix: str = "_lib", subdir: Optional[str] = None,
+                     file_suffix: str = "", duration_map: Optional[Dict[int, float]] = None, index_offset: int = 1,
+                     always_append_duration: bool = False) -> List[str]:
         base = Path(output_dir) / subdir if subdir else Path(output_dir)
         base.mkdir(parents=True, exist_ok=True)
         saved: List[str] = []
         for i, (lo, hi) in enumerate(spans):
-            label = "human" if (bool(segment_is_vocal[i]) if i < len(segment_is_vocal) else True) else "music"
-            suffix = file_suffix
-            if duration_map is not None and i in duration_map:
-                tag = f"_{max(0.0, float(duration_map[i])):.1f}"
-                suffix = f"{file_suffix}{tag}" if file_suffix else tag
-            path = _export_path(base / f"segment_{i + index_offset:03d}_{label}{suffix}", "wav")
-            saved.append(str(track.write(path, lo, hi)))
+            stem = self._stem(i, hi - lo, track.sample_rate, segment_is_vocal=segment_is_vocal, lib_flags=lib_flags,
+                              lib_suffix=lib_suffix, file_suffix=file_suffix, duration_map=duration_map, index_offset=index_offset,
+                              always_append_duration=always_append_duration)
+            saved.append(str(track.write(_export_path(base / stem, "wav"), lo, hi)))
         return saved
 
-    def export_full_track(self, track: PackedTrack, output_base: Path) -> str:
+    def export_full_track(self, audio, output_base: Path, *, export_format: str = "wav",
+                          export_options: Optional[Dict[str, object]] = None) -> str:
+        """`audio`: a PackedTrack (device path) or a mono array (the reference's form)."""
         Path(output_base).parent.mkdir(parents=True, exist_ok=True)
-        return str(track.write(_export_path(Path(output_base), "wav")))
+        if isinstance(audio, PackedTrack):
+            return str(audio.write(_export_path(Path(output_base), ensure_supported_format(export_format))))
+        return str(export_audio(audio, self.sample_rate, Path(output_base), export_format, options=export_options))
 
 
 __all__ = ["ensure_supported_format", "build_export_options", "export_audio", "ExportResult", "SegmentExporter", "PackedTrack",

@@ -233,3 +233,61 @@ def test_zero_beat_base_score_switches_beat_candidates_off():
     finally:
         reset_runtime_config()
     assert got == []
+
+
+def test_pool_merge_dedupes_neighbours_and_keeps_every_source():
+    """reference tests/unit/test_candidate_pool_fusion.py:107-129: the better-scored member names the merged candidate."""
+    acoustic = CutCandidate(t=6.04, score=0.4, source=CandidateSource.ACOUSTIC_PAUSE, reasons=["legacy_acoustic"], meta={"pause_type": "true_pause"})
+    sentence = CutCandidate(t=6.0, score=0.85, source=CandidateSource.SENTENCE_END, reasons=["sentence_end", "punctuation_end"], meta={"text": "phrase."})
+    merged = VocalPhraseBoundaryDetector(sample_rate=44100)._merge_candidate_pool([acoustic], [sentence], tolerance_s=0.12)
+    assert len(merged) == 1 and merged[0].t == 6.0 and merged[0].source == CandidateSource.SENTENCE_END
+    assert set(merged[0].meta["sources"]) == {"acoustic_pause", "sentence_end"} and merged[0].meta["source_count"] == 2
+
+
+def test_legacy_pool_keeps_a_breath_typed_pause_as_an_acoustic_candidate(tmp_path):
+    """reference tests/unit/test_candidate_pool_fusion.py:176-222."""
+    class OneBreathMddPause:
+        def detect_pure_vocal_pauses(self, *args, **kwargs):
+            return [NS(start_time=5.8, end_time=6.2, cut_point=6.0, confidence=0.8, duration=0.4, pause_type="breath_mdd")]
+
+    set_runtime_config({"vpbd.candidate_pool": "legacy", "vpbd.breath_score_scale": 0.0, "lyrics_alignment.enabled": False,
+                        "global_planner.hard_min_s": 2.0, "global_planner.hard_max_s": 8.0, "global_planner.target_min_s": 5.0,
+                        "global_planner.target_max_s": 7.0})
+    try:
+        vocal = np.zeros(int(44100 * 12.0), dtype=np.float32)
+        res = VocalPhraseBoundaryDetector(sample_rate=44100).detect(
+            mode="vpbd_acoustic", vocal_track=vocal, original_audio=vocal.copy(), pure_vocal_detector=OneBreathMddPause(),
+            feature_cache=None, vad_segments=[], input_path=str(tmp_path / "sample.wav"), output_dir=str(tmp_path / "out"))
+    finally:
+        reset_runtime_config()
+    counts = res.boundary_detection["candidate_counts"]
+    assert res.boundary_detection["candidate_pool"] == "legacy" and counts["acoustic"] == 1 and counts["merged"] == 1
+    assert res.selected_candidates[0].source == CandidateSource.ACOUSTIC_PAUSE
+
+
+def test_segment_file_names_carry_label_lib_marker_and_duration(monkeypatch, tmp_path):
+    """reference tests/unit/test_legacy_mode_regression.py:37-70 (exporter row)."""
+    from pathlib import Path
+
+    import audio_cut_amd.utils.audio_export as export_module
+    stems: List[str] = []
+
+    def record_only(audio, sample_rate, base_path, format_name, *, options=None):
+        stems.append(Path(base_path).name)
+        return f"{base_path}.{format_name}"
+
+    monkeypatch.setattr(export_module, "export_audio", record_only)
+    ex = export_module.SegmentExporter(sample_rate=44100)
+    files = ex.export_segments([np.zeros(44100, dtype=np.float32)] * 2, str(tmp_path), segment_is_vocal=[True, False], export_format="wav",
+                               export_options={}, lib_flags=[True, False], duration_map={0: 2.0, 1: 3.5})
+    assert stems == ["segment_001_human_lib_2.0", "segment_002_music_3.5"]
+    assert [Path(f).name for f in files] == ["segment_001_human_lib_2.0.wav", "segment_002_music_3.5.wav"]
+    monkeypatch.undo()
+    # the real writer: same names on disk, bytes equal to the span form the device path uses
+    audio = np.linspace(-0.5, 0.5, 2000, dtype=np.float32)
+    a = ex.export_segments([audio[:800], audio[800:]], str(tmp_path / "a"), segment_is_vocal=[True, False], export_format="wav",
+                           export_options={}, always_append_duration=True)
+    b = ex.export_spans(export_module.PackedTrack(audio, 44100), [(0, 800), (800, 2000)], str(tmp_path / "b"),
+                        segment_is_vocal=[True, False], always_append_duration=True)
+    assert [Path(f).name for f in a] == [Path(f).name for f in b] == ["segment_001_human_0.0.wav", "segment_002_music_0.0.wav"]
+    assert all(Path(x).read_bytes() == Path(y).read_bytes() for x, y in zip(a, b))
