@@ -46,6 +46,10 @@ def _remove_true_runs(mask: np.ndarray, max_len: int) -> np.ndarray:
     return out
 
 
+PRECISION_GUARD_AVG_MS = 150.0     # reference `seamless_splitter.py:66-67`
+PRECISION_GUARD_P95_MS = 220.0
+
+
 class SeamlessSplitter:
     SUPPORTED_MODES = ("v2.2_mdd", "v2.1", "vpbd_acoustic", "vpbd_asr")
 
@@ -144,6 +148,9 @@ class SeamlessSplitter:
                                                    mix_dev=state.get("mix"), vocal_dev=state.get("vocal"))
         self._last_suppressed_cut_points = list(refine.suppressed_points or [])
         bounds = sorted(set(refine.sample_boundaries))
+        if is_vpbd:         # `:494-499`: the planner block records where the guards moved each selected candidate
+            from ..cutting.global_cut_planner import apply_guard_shift_metadata
+            vpbd.boundary_detection["planner"] = dict(apply_guard_shift_metadata(vpbd.planner_result, self._last_guard_adjustments_raw).metadata)
         if protected:       # `:501-508`
             total = len(original_audio)
             aug = set(int(b) for b in bounds)
@@ -157,11 +164,30 @@ class SeamlessSplitter:
         policy = self._apply_boundary_policy(bounds, vocal_track, len(original_audio), cache, vocal_dev=state.get("vocal"))
         result.update(policy)
         result["timings_policy_s"] = time.perf_counter() - t3
+        kept = list(self._last_guard_adjustments_raw)               # after the layout refiner's filter (`:602`)
+        stats = self._guard_shift_stats(kept)
         result.update({"sample_boundaries": bounds, "refine_boundaries": list(refine.sample_boundaries),
                        "cut_candidates": cut_candidates,
-                       "guard_adjustments": list(refine.adjustments or []),
+                       "guard_adjustments": kept, "guard_adjustments_unfiltered": list(refine.adjustments or []),
+                       "guard_shift_stats": stats,
+                       "precision_guard_ok": bool(stats["avg_shift_ms"] <= PRECISION_GUARD_AVG_MS and stats["p95_shift_ms"] <= PRECISION_GUARD_P95_MS),
+                       "precision_guard_threshold_ms": {"avg": PRECISION_GUARD_AVG_MS, "p95": PRECISION_GUARD_P95_MS},
                        "timings": {"separate_s": t_sep, "detect_s": t_det, "finalize_s": t_fin}})
         return result
+
+    @staticmethod
+    def _guard_shift_stats(adjustments: Sequence) -> Dict[str, float]:
+        """`_set_guard_adjustments` (`:2423-2470`): how far the quiet guards moved the kept cuts, in ms."""
+        total = np.array([a.final_shift_ms for a in adjustments], dtype=float)
+        if total.size == 0:
+            return {"avg_shift_ms": 0.0, "max_shift_ms": 0.0, "avg_guard_only_shift_ms": 0.0, "avg_vocal_guard_shift_ms": 0.0,
+                    "avg_mix_guard_shift_ms": 0.0, "p95_shift_ms": 0.0, "count": 0}
+        vocal = np.array([a.guard_shift_ms for a in adjustments], dtype=float)
+        mean_pos = lambda v: float(sum(x for x in v.tolist() if x > 0) / max(1, int((v > 0).sum()))) if (v > 0).any() else 0.0
+        return {"avg_shift_ms": float(sum(abs(x) for x in total.tolist()) / total.size), "max_shift_ms": float(np.abs(total).max()),
+                "avg_guard_only_shift_ms": mean_pos(total), "avg_vocal_guard_shift_ms": mean_pos(vocal),
+                "avg_mix_guard_shift_ms": mean_pos(total - vocal), "p95_shift_ms": float(np.percentile(np.abs(total), 95.0)),
+                "count": int(total.size)}
 
     # ------------------------------------------------------------------------------------------
     def _single_segment_fields(self, vocal_track: np.ndarray, n_samples: int, vocal_dev=None) -> Dict:

@@ -81,7 +81,8 @@ def test_separate_and_segment_end_to_end_from_48k_stereo_wav(hip_ctx, tmp_path):
     with wave.open(str(src), "wb") as w:
         w.setnchannels(2); w.setsampwidth(2); w.setframerate(48000); w.writeframes(pcm.tobytes())
     out_dir = tmp_path / "out"
-    res = api.separate_and_segment(input_uri=str(src), export_dir=str(out_dir), export_manifest=True)
+    ret = api.separate_and_segment(input_uri=str(src), export_dir=str(out_dir), export_manifest=True)
+    res = api.last_result()
     n = int(round(st48.shape[1] * 147 / 160 + 0.49999))
     cuts = res["cut_points_samples"]
     assert cuts[0] == 0 and abs(cuts[-1] - n) <= 1 and cuts == sorted(set(cuts))
@@ -93,11 +94,29 @@ def test_separate_and_segment_end_to_end_from_48k_stereo_wav(hip_ctx, tmp_path):
             total += w.getnframes()
             assert abs(w.getnframes() / SR - d) < 1e-9
     assert total == cuts[-1]                                                  # the mix segments tile the whole track
+    # the call returns the manifest (reference `api.py:115-131`); the file on disk is the same document
     man = json.loads((out_dir / "SegmentManifest.json").read_text())
-    assert man["version"] == "v2.2_mdd" and man["audio"]["sr"] == SR and man["audio"]["hash"].startswith("sha256:")
-    assert man["cuts"]["samples"] == cuts and len(man["segments"]) == res["num_segments"]
-    assert set(man["artifacts"]) == {"music_segments", "human_segments", "vocal_full", "instrumental_full"}
+    assert ret["manifest_path"] == (out_dir / "SegmentManifest.json").resolve().as_posix()
+    assert man["version"] == ret["version"] == "v2.2_mdd" and man["audio"]["sr"] == SR and man["audio"]["hash"].startswith("sha256:")
+    assert man["cuts"]["samples"] == cuts and len(man["segments"]) == res["num_segments"] == man["stats"]["num_segments"]
+    assert set(man["artifacts"]) == {"music_segments", "human_segments", "vocal_full", "instrumental_full", "all", "output_dir"}
     assert man["segments"][0]["mix_path"].startswith("segment_001_") and "gpu" in man
+    assert man["qa_report"]["segments_count"] == res["num_segments"] and man["guard"]["precision_ok"] in (True, False)
+    assert man["guard"]["shift_stats"]["count"] == len(man["guard"]["adjustments"]) and man["guard"]["threshold_ms"] == {"avg": 150.0, "p95": 220.0}
+    assert man["audio"]["duration"] == cuts[-1] / SR and isinstance(man["timings_ms"]["total"], int)
     # the full vocal file holds the separator's stem, quantised
     voc, sr2 = api.load_audio_mono(res["full_vocal_file"])
     assert sr2 == SR and len(voc) == cuts[-1]
+    # VPBD through the same entry: the manifest carries the pool's blocks and annotated cuts, and survives JSON
+    out2 = tmp_path / "out_vpbd"
+    ret2 = api.separate_and_segment(input_uri=str(src), export_dir=str(out2), mode="vpbd_acoustic", export_types=["mix_segments"],
+                                    export_manifest=True, manifest_filename="m.json")
+    man2 = json.loads((out2 / "m.json").read_text())
+    assert man2["version"] == "vpbd_acoustic" and man2["export_plan"] == ["mix_segments"] and set(man2["artifacts"]) == {"music_segments", "all", "output_dir"}
+    assert man2["boundary_detection"]["actual_mode"] == "vpbd_acoustic" and man2["lyrics_alignment"]["fallback_reason"] is None
+    planner = ret2["boundary_detection"]["planner"]
+    assert "guard_shift_ms_by_raw_time" in planner and "final_time_by_raw_time" in planner
+    tagged = [c for c in man2["cuts"]["final"] if isinstance(c, dict) and "source" in c]
+    assert len(tagged) == sum(1 for c in ret2["cuts"]["final"] if isinstance(c, dict) and "source" in c)
+    assert man2["cuts"]["samples"][0] == 0 and man2["cuts"]["samples"][-1] == cuts[-1]
+    assert man2["qa_report"]["fallback_reason"] is None and man2["qa_report"]["segments_count"] == len(man2["segments"])

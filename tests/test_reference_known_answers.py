@@ -291,3 +291,100 @@ def test_segment_file_names_carry_label_lib_marker_and_duration(monkeypatch, tmp
                         segment_is_vocal=[True, False], always_append_duration=True)
     assert [Path(f).name for f in a] == [Path(f).name for f in b] == ["segment_001_human_0.0.wav", "segment_002_music_0.0.wav"]
     assert all(Path(x).read_bytes() == Path(y).read_bytes() for x, y in zip(a, b))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Manifest row: `_build_manifest` and the QA report, from the reference's `tests/unit/test_api_manifest.py`,
+# `test_qa_report.py` and `test_legacy_mode_regression.py:73-108`.  Input files are written with the stdlib `wave` module.
+# ----------------------------------------------------------------------------------------------------------------------
+def _silent_wav(path, seconds: float):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(44100); w.writeframes(b"\x00\x00" * int(44100 * seconds))
+    return path
+
+
+def _one_segment_result(seconds: float) -> dict:
+    return {"success": True, "export_plan": [], "cut_points_sec": [0.0, seconds], "cut_points_samples": [0, int(44100 * seconds)],
+            "segment_labels": ["human"], "segment_durations": [seconds], "segment_vocal_flags": [True]}
+
+
+def test_manifest_plain_shape_without_vpbd_blocks(tmp_path):
+    from audio_cut_amd.api import _build_manifest
+    man = _build_manifest(result=_one_segment_result(2.0), input_path=_silent_wav(tmp_path / "song.wav", 2.0), export_dir=tmp_path,
+                          mode="v2.2_mdd", sample_rate=44100, channels=1, layout_cfg={})
+    assert man["cuts"]["final"] == [0.0, 2.0] and man["version"] == "v2.2_mdd"
+    assert "lyrics_alignment" not in man and "boundary_detection" not in man and "lyrics" not in man["segments"][0]
+    assert set(man) == {"version", "success", "job", "export_plan", "audio", "layout_cfg", "cuts", "segments", "artifacts", "guard",
+                        "separation", "timings_ms", "stats", "qa_report"}
+    assert man["guard"] == {"shift_stats": {}, "adjustments": [], "precision_ok": True, "threshold_ms": {}}
+    assert man["layout_cfg"] == {"applied": False} and man["audio"]["duration"] == 2.0 and man["audio"]["hash"].startswith("sha256:")
+
+
+def test_manifest_passes_auto_profile_and_smart_segmentation_through(tmp_path):
+    from audio_cut_amd.api import _build_manifest
+    src = _silent_wav(tmp_path / "song.wav", 2.0)
+    res = _one_segment_result(2.0) | {"auto_profile": {"style": "pop", "confidence": 0.7, "bpm": 108.0, "mdd": 0.38,
+                                                       "applied_overrides": ["global_planner.target_min_s"]}}
+    man = _build_manifest(result=res, input_path=src, export_dir=tmp_path, mode="vpbd_asr", sample_rate=44100, channels=1, layout_cfg={})
+    assert man["auto_profile"]["style"] == "pop" and man["auto_profile"]["applied_overrides"] == ["global_planner.target_min_s"]
+    res = {"success": True, "method": "smart_segment_v2", "export_plan": [], "cut_points_sec": [0.0, 2.0, 4.0],
+           "cut_points_samples": [0, 88200, 176400], "segment_labels": ["human", "music"], "segment_durations": [2.0, 2.0],
+           "segment_vocal_flags": [True, False], "bpm": 120.0, "bar_duration_s": 2.0, "density": "medium", "silence_boundaries": [2.0]}
+    man = _build_manifest(result=res, input_path=src, export_dir=tmp_path, mode="librosa_onset", sample_rate=44100, channels=1, layout_cfg={})
+    assert man["version"] == "librosa_onset"
+    assert man["smart_segmentation"] == {"method": "smart_segment_v2", "bpm": 120.0, "bar_duration_s": 2.0, "density": "medium",
+                                         "silence_boundaries": [2.0]}
+
+
+def test_manifest_annotates_cuts_with_planner_candidates(tmp_path):
+    """`_build_final_cuts`: a selected candidate followed through the guard's move names the cut it became."""
+    from audio_cut_amd.api import _build_manifest
+    res = {"success": True, "export_plan": [], "cut_points_sec": [0.0, 4.1, 8.0], "cut_points_samples": [0, 180810, 352800],
+           "segment_labels": ["human", "human"], "segment_durations": [4.1, 3.9], "segment_vocal_flags": [True, True],
+           "boundary_detection": {"selected": [{"t": 4.0, "score": 0.8, "source": "breath", "features": {"beat_affinity": 0.9},
+                                                "reasons": ["vpbd_score"], "meta": {"sources": ["breath", "beat"]}}],
+                                  "planner": {"final_time_by_raw_time": {4.0: 4.1}, "guard_shift_ms_by_raw_time": {4.0: 100.0}}}}
+    man = _build_manifest(result=res, input_path=_silent_wav(tmp_path / "song.wav", 8.0), export_dir=tmp_path, mode="vpbd_acoustic",
+                          sample_rate=44100, channels=1, layout_cfg={"enable": True})
+    assert man["cuts"]["final"][0] == {"t": 0.0} and man["cuts"]["final"][2] == {"t": 8.0}
+    assert man["cuts"]["final"][1] == {"t": 4.1, "score": 0.8, "source": "breath", "features": {"beat_affinity": 0.9},
+                                       "reasons": ["vpbd_score"], "meta": {"sources": ["breath", "beat"]}, "guard_shift_ms": 100.0}
+    qa = man["qa_report"]
+    assert qa["breath_cut_ratio"] == 1.0 and qa["beat_aligned_ratio"] == 1.0 and qa["avg_boundary_score"] == 0.8
+    assert qa["guard_shift_p50_ms"] == 100.0 and man["layout_cfg"] == {"enable": True, "applied": False}
+
+
+def test_qa_report_known_answers(tmp_path):
+    import pytest
+    from audio_cut_amd.api import _build_manifest
+    from audio_cut_amd.qa_report import build_qa_report
+    report = build_qa_report({
+        "audio": {"duration": 20.0}, "segments": [{"duration": 6.0}, {"duration": 10.0}, {"duration": 16.0}],
+        "cuts": {"final": [{"t": 0.0}, {"t": 1.2, "score": 0.4, "guard_shift_ms": 10.0, "source": "breath"},
+                           {"t": 8.0, "score": 0.8, "guard_shift_ms": 30.0, "source": "beat", "features": {"beat_affinity": 1.0}}, {"t": 20.0}]},
+        "lyrics_alignment": {"fallback_reason": "timeout", "timeline": {
+            "duration_s": 20.0,
+            "words": [{"text": "hello", "start_s": 1.0, "end_s": 1.5, "confidence": 0.8}, {"text": "world", "start_s": 6.0, "end_s": 7.0, "confidence": None}],
+            "vad_regions": [{"start_s": 1.0, "end_s": 2.0, "confidence": 0.9, "kind": "singing"}]}}})
+    assert report["segments_count"] == 3 and report["median_segment_s"] == 10.0
+    assert report["segment_5_15_pass_rate"] == pytest.approx(2 / 3)
+    assert report["cut_inside_word_rate"] == 0.5 and report["cut_inside_singing_rate"] == 0.5
+    assert report["avg_boundary_score"] == 0.6 and report["lyrics_coverage_ratio"] == 0.075 and report["asr_avg_confidence"] == 0.8
+    assert report["guard_shift_p50_ms"] == 20.0 and report["guard_shift_p95_ms"] == 29.0 and report["fallback_reason"] == "timeout"
+    assert report["breath_cut_ratio"] == 0.5 and report["beat_aligned_ratio"] == 0.5
+    man = _build_manifest(result=_one_segment_result(8.0), input_path=_silent_wav(tmp_path / "song.wav", 8.0), export_dir=tmp_path,
+                          mode="v2.2_mdd", sample_rate=44100, channels=1, layout_cfg={})
+    assert man["qa_report"]["segments_count"] == 1 and man["qa_report"]["segment_5_15_pass_rate"] == 1.0
+
+
+def test_guard_shift_stats_known_answer():
+    """`_set_guard_adjustments` arithmetic (reference `seamless_splitter.py:2423-2470`) on a hand-made set of adjustments."""
+    adj = [CutAdjustment(raw_time=1.0, guard_time=1.1, final_time=1.15, score=1.0, guard_shift_ms=100.0, final_shift_ms=150.0),
+           CutAdjustment(raw_time=5.0, guard_time=5.0, final_time=4.95, score=1.0, guard_shift_ms=0.0, final_shift_ms=-50.0),
+           CutAdjustment(raw_time=9.0, guard_time=9.3, final_time=9.3, score=1.0, guard_shift_ms=300.0, final_shift_ms=300.0)]
+    st = SeamlessSplitter._guard_shift_stats(adj)
+    assert st["count"] == 3 and st["max_shift_ms"] == 300.0 and st["avg_shift_ms"] == (150.0 + 50.0 + 300.0) / 3
+    assert st["avg_guard_only_shift_ms"] == 225.0 and st["avg_vocal_guard_shift_ms"] == 200.0 and st["avg_mix_guard_shift_ms"] == 50.0
+    assert st["p95_shift_ms"] == float(np.percentile([150.0, 50.0, 300.0], 95.0))
+    assert SeamlessSplitter._guard_shift_stats([])["count"] == 0
