@@ -7,19 +7,17 @@ from enum import Enum
 from typing import Any, Dict, List
 
 
-class CandidateSource(str, Enum):
-    ACOUSTIC_PAUSE = "acoustic_pause"
-    MDD_VALLEY = "mdd_valley"
-    BREATH = "breath"
-    LYRICS_GAP = "lyrics_gap"
-    SENTENCE_END = "sentence_end"
-    MVAD_BOUNDARY = "mvad_boundary"
-    BEAT = "beat"
-    RESCUE = "rescue"
+_SOURCE_NAMES = ("acoustic_pause", "mdd_valley", "breath", "lyrics_gap", "sentence_end", "mvad_boundary", "beat", "rescue")
+# str-valued enum, members named after their values in upper case (ACOUSTIC_PAUSE = "acoustic_pause", ...)
+CandidateSource = Enum("CandidateSource", {name.upper(): name for name in _SOURCE_NAMES}, type=str, module=__name__)
+
+_COPIED_FIELDS = (("reasons", list), ("features", dict), ("meta", dict))
 
 
 @dataclass
 class CutCandidate:
+    """A boundary proposal at `t` seconds, `score` kept inside [0, 1], `source` coerced to the enum."""
+
     t: float
     score: float
     source: CandidateSource
@@ -28,14 +26,15 @@ class CutCandidate:
     meta: Dict[str, Any] = field(default_factory=dict)
 
     def __post_init__(self) -> None:
-        self.t = float(self.t)
-        self.score = min(1.0, max(0.0, float(self.score)))
-        if not isinstance(self.source, CandidateSource):
-            self.source = CandidateSource(str(self.source))
+        self.t, score = float(self.t), float(self.score)
+        score = score if score > 0.0 else 0.0            # NaN lands on 0, as min(1, max(0, nan)) does
+        self.score = score if score < 1.0 else 1.0
+        self.source = self.source if isinstance(self.source, CandidateSource) else CandidateSource(str(self.source))
 
     def to_dict(self) -> Dict[str, Any]:
-        return {"t": self.t, "score": self.score, "source": self.source.value, "reasons": list(self.reasons),
-                "features": dict(self.features), "meta": dict(self.meta)}
+        out: Dict[str, Any] = {"t": self.t, "score": self.score, "source": self.source.value}
+        out.update((name, kind(getattr(self, name))) for name, kind in _COPIED_FIELDS)
+        return out
 
 
 def adapt_legacy_acoustic_candidates(raw_candidates, *, source: CandidateSource = CandidateSource.ACOUSTIC_PAUSE,
