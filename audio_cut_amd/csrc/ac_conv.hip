@@ -10,8 +10,11 @@
 //
 // Implicit GEMM, D[co][pixel] = sum_k A[co][k] B[k][pixel]:  A = weights (M = 48 output channels per workgroup,
 // pre-packed on the host in MFMA fragment order), B = activations (N = an 8 x 32 pixel tile, 4 waves x 64 pixels).
-// K is walked in blocks of 16 input channels; inside a block the 9 taps are paired into 5 k-steps of 32
-// (lane groups 0-1 carry tap 2p, groups 2-3 tap 2p+1; the 10th slot has zero weights).  Per block the
+// K is walked in blocks of 16 input channels; inside a block taps 0..7 are paired into 4 k-steps of 32 (lane groups 0-1
+// carry tap 2p, groups 2-3 tap 2p+1).  Tap 8 of an even block is paired with tap 8 of the next block: the even block only
+// keeps its tap-8 activation fragments in registers (lane groups 0-1), the odd block reads its own into lane groups 2-3 of
+// the same registers and issues the shared k-step, so two blocks cost 9 k-steps instead of 10 (a trailing unpaired block
+// issues its tap 8 against zero weights in lane groups 2-3).  Per block the
 // (8+2) x (32+8) x 16 input patch is converted to f16 hi/lo once and staged in LDS as [pixel][channel].
 // Staging loads are aligned float4 (a 40-column span per patch row); the epilogue (+ bias, optional ReLU) goes through
 // LDS so that every output row segment leaves as one 128-byte line.
@@ -44,6 +47,7 @@ __device__ inline unsigned short f16_bits(_Float16 h) { return __builtin_bit_cas
 #define CV_ACT_ITERS ((CV_ITEMS + 255) / 256)                              // 2
 __device__ inline int cv_phys(int c) { return c ^ (((c >> 2) & 1) << 1); } // staged column of logical column c (0..39)
 #define CV_WFRAGS (5 * 2 * CV_MT * 64)                                     // 1920 16-byte weight fragments per stage
+#define CV_WFRAGS_PAIRS (4 * 2 * CV_MT * 64)                               // 1536: the four in-block tap pairs
 #define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
 #define CV_OUT_STRIDE (CV_TW + 4)                                          // floats per (co, row) line of the output staging
 
@@ -88,6 +92,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     for (int m = 0; m < CV_MT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 k8h[4], k8l[4];               // tap-8 activation fragments carried from an even channel block into the next one
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { k8h[q] = (f16x8)(_Float16)0; k8l[q] = (f16x8)(_Float16)0; }
 
     const int g = lane >> 4, px = lane & 15;
     const int ci_off = 8 * (g & 1);
@@ -126,10 +133,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
 
     auto prefetch = [&](int cb) {
         const f16x8* wcb = wbase + (size_t)cb * CV_WFRAGS;
+        const int nfr = (!(cb & 1) && cb + 1 < n_cb) ? CV_WFRAGS_PAIRS : CV_WFRAGS;     // an even block with a partner has no fifth k-step
 #pragma unroll
         for (int i = 0; i < CV_W_ITERS; ++i) {
             const int e = tid + 256 * i;
-            if (e < CV_WFRAGS) pre_w[i] = wcb[e];
+            if (e < nfr) pre_w[i] = wcb[e];
         }
 #pragma unroll
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
@@ -145,10 +153,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     prefetch(0);
     for (int cb = 0; cb < n_cb; ++cb) {
         __syncthreads();                 // previous stage fully consumed
+        const bool odd = cb & 1;
+        const bool shared_step = odd || cb + 1 >= n_cb;      // this block issues the tap-8 k-step (its own half, or both halves)
+        const int nfr = shared_step ? CV_WFRAGS : CV_WFRAGS_PAIRS;
 #pragma unroll
         for (int i = 0; i < CV_W_ITERS; ++i) {
             const int e = tid + 256 * i;
-            if (e < CV_WFRAGS) s_w[e] = pre_w[i];
+            if (e < nfr) s_w[e] = pre_w[i];
         }
 #pragma unroll
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
@@ -189,9 +200,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         __syncthreads();
         if (cb + 1 < n_cb) prefetch(cb + 1);   // global loads of the next stage fly under this stage's MFMAs
 #pragma unroll
-        for (int pair = 0; pair < 5; ++pair) {
-            int tap = pair * 2 + (g >> 1);
-            if (tap > 8) tap = 8;                          // padded slot: weights are zero, any finite B will do
+        for (int pair = 0; pair < 4; ++pair) {
+            const int tap = pair * 2 + (g >> 1);
             const int dy = tap / 3, dx = tap - dy * 3;
             f16x8 ah[CV_MT], al[CV_MT];
 #pragma unroll
@@ -210,6 +220,34 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                     acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][q], 0, 0, 0);
                     acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][q], 0, 0, 0);
                     acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][q], 0, 0, 0);
+                }
+            }
+        }
+        // tap 8 (dy = dx = 2): an even block loads its fragments into every lane group (groups 0-1 are the ones that count);
+        // an odd block overwrites groups 2-3 only, so k 0..15 of the shared step is the even block, k 16..31 the odd one
+        if (!odd || g >= 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+                const int off = ((ty + 2) * CV_LW + cv_phys(tx + 2 + 3)) * CV_PIX_STRIDE + ci_off;
+                k8h[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+                k8l[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+            }
+        }
+        if (shared_step) {
+            f16x8 ah[CV_MT], al[CV_MT];
+#pragma unroll
+            for (int m = 0; m < CV_MT; ++m) {
+                ah[m] = s_w[((4 * 2 + 0) * CV_MT + m) * 64 + lane];
+                al[m] = s_w[((4 * 2 + 1) * CV_MT + m) * 64 + lane];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int m = 0; m < CV_MT; ++m) {
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], k8l[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], k8h[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], k8h[q], acc[m][q], 0, 0, 0);
                 }
             }
         }

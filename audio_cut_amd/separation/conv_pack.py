@@ -4,8 +4,11 @@ float32 weights [C_out, C_in, 3, 3] (BatchNorm already folded) are scaled by a p
 halves stay in the normal float16 range; the kernel multiplies the accumulator by the exact inverse), split
 into float16 hi/lo parts (hi = f16(w), lo = f16(w - hi), round-to-nearest-even) and laid out in the A-operand
 fragment order of `v_mfma_f32_16x16x32_f16`: lane l holds A[row = l & 15][k = 8 (l >> 4) + j], j = 0..7.
-K walks blocks of 16 input channels; inside a block the 9 taps are paired into 5 k-steps (lane groups 0-1:
-tap 2p, groups 2-3: tap 2p+1, the 10th slot is zero).
+K walks blocks of 16 input channels; inside a block taps 0..7 are paired into 4 k-steps (lane groups 0-1: tap 2p,
+groups 2-3: tap 2p+1).  The fifth k-step of an ODD block carries tap 8 of the block before it in lane groups 0-1 and
+its own tap 8 in groups 2-3 (the kernel keeps the even block's activation fragments in registers), so an even block
+with a partner has an all-zero, never-loaded fifth step; a trailing unpaired block keeps its tap 8 in groups 0-1 against
+zeros in groups 2-3.
 Result: (uint16 array [C_out/48][C_in/16][5][2 (hi, lo)][3 (row tiles)][64 lanes][8], w_unscale).
 """
 from __future__ import annotations
@@ -49,10 +52,20 @@ def pack_conv3x3(weight: np.ndarray) -> Tuple[np.ndarray, float]:
             rows = cob * 48 + mt * 16 + r                                        # [64]
             for cb in range(ci // 16):
                 cols = cb * 16 + 8 * (g & 1)[:, None] + j[None, :]               # [64, 8]
-                for pair in range(5):
+                for pair in range(4):
                     tap = pair * 2 + (g >> 1)                                    # [64]
                     for part in range(2):
                         out[cob, cb, pair, part, mt] = taps[part, rows[:, None], cols, tap[:, None]]
+                n_cb = ci // 16
+                if cb & 1:                     # shared step: k 0..15 = tap 8 of block cb - 1, k 16..31 = tap 8 of block cb
+                    cols8 = (cb - 1 + (g >> 1))[:, None] * 16 + 8 * (g & 1)[:, None] + j[None, :]
+                    tap8 = np.full(64, 8)
+                elif cb + 1 < n_cb:            # even block with a partner: nothing of its own in the fifth step
+                    cols8, tap8 = cols, np.full(64, 9)
+                else:                          # trailing unpaired block: groups 0-1 tap 8, groups 2-3 the zero slot
+                    cols8, tap8 = cols, 8 + (g >> 1)
+                for part in range(2):
+                    out[cob, cb, 4, part, mt] = taps[part, rows[:, None], cols8, tap8[:, None]]
     return out, 1.0 / scale
 
 

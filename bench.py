@@ -59,8 +59,9 @@ def cpu_baseline(sample_s: float, weights, spec) -> dict:
 
 DOMINANT = "k_conv3x3_f16x3"           # audio_cut_amd/csrc/ac_conv.hip; rocprofv3 prints it as `void k_conv3x3_f16x3<true>(...)`
 F16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_16x16x32_f16)
-# MFMA instructions the split issues per algorithmic FLOP: 3 products (hi*hi + hi*lo + lo*hi) on 10 tap slots for 9 taps
-F16X3_ISSUE_FACTOR = 3.0 * 10.0 / 9.0
+# MFMA FLOPs the split issues per algorithmic FLOP: 3 products (hi*hi + hi*lo + lo*hi); tap 8 of two consecutive 16-channel
+# blocks shares one k-step, so only a trailing unpaired block (C/16 odd: C = 48, 144, 240) pads - 1.5 % FLOP-weighted over the U-Net
+F16X3_ISSUE_FACTOR = 3.0 * 1.015
 
 
 def roofline_conv(probe, conv_ms: float, conv_flops: float, elapsed: float) -> dict:
@@ -89,9 +90,9 @@ def roofline_conv(probe, conv_ms: float, conv_flops: float, elapsed: float) -> d
         "mfma_issued_tflops": round(achieved * F16X3_ISSUE_FACTOR, 2),
         "frac_mfma_issued": round(achieved * F16X3_ISSUE_FACTOR / F16_MFMA_PEAK_TFLOPS, 4),
         "note": "achieved/frac count algorithmic f32-conv FLOPs against the dense f16 MFMA peak the kernel runs on; the split issues "
-                "3.33x as many f16 MFMA FLOPs (mfma_issued_tflops) to deliver f32-class products, i.e. 2x the chip's f32 MFMA "
-                "peak (frac_of_f32_matrix_peak); an MFMA-only build of the same instruction stream tops out at ~1487 TFLOP/s "
-                "issued on random data (DESIGN.md 3.1)",
+                "3.05x as many f16 MFMA FLOPs (mfma_issued_tflops) to deliver f32-class products, i.e. 2x the chip's f32 MFMA "
+                "peak (frac_of_f32_matrix_peak); a bare v_mfma_f32_16x16x32_f16 loop sustains 1880 TFLOP/s under this socket's "
+                "power cap (profiles/r01f_mfma_power_probe.log, DESIGN.md 7)",
         "launches": len(probe), "avg_launch_ms": round(conv_ms / n, 4), "flops_per_launch": conv_flops / n,
         "share_of_step": round(conv_ms / 1e3 / max(1e-9, elapsed), 3),
     }
