@@ -1,5 +1,6 @@
 """Writes tests/golden/c2_full_oracle.npz: the CPU oracle's result on the full BASELINE configs[1] track (4-min C2 song,
-seed 2, seeded synthetic weights seed 0).  The oracle takes minutes on the CPU, so the GPU test compares against this
+seed 2, seeded synthetic weights seed 0); with arguments `SECONDS SEED NAME`, another track of the same generator into
+tests/golden/NAME.npz (c2_150s_seed11_oracle.npz was written with `150 11 c2_150s_seed11_oracle`).  The oracle takes minutes on the CPU, so the GPU test compares against this
 fixture instead of re-running it (the same comparison, run live on the GPU box, is scratch/c2_full.py).
 Run from the repo root:  python tests/golden/make_c2_full.py"""
 import sys
@@ -17,14 +18,15 @@ from oracle import e2e as OE, refine as OR  # noqa: E402
 
 if __name__ == "__main__":
     OR.LEGACY_PROMOTION = True
-    mix = signals.c2_song(240.0, seed=2)
+    seconds, seed, name = (float(sys.argv[1]), int(sys.argv[2]), sys.argv[3]) if len(sys.argv) > 3 else (240.0, 2, "c2_full_oracle")
+    mix = signals.c2_song(seconds, seed=seed)
     w = synth_weights(TfcTdfSpec(), seed=0)
     t0 = time.time()
     ref = OE.run_track(mix, 44100, w)
     print(f"oracle: {time.time() - t0:.1f} s, {len(ref.sample_boundaries)} boundaries, {len(ref.policy.cuts)} manifest cuts")
     sec = 44100
     nsec = len(mix) // sec
-    np.savez_compressed(ROOT / "tests" / "golden" / "c2_full_oracle.npz",
+    np.savez_compressed(ROOT / "tests" / "golden" / f"{name}.npz", seconds=np.float64(seconds), seed=np.int64(seed),
                         sample_boundaries=np.asarray(ref.sample_boundaries, dtype=np.int64),
                         cuts=np.asarray(ref.policy.cuts, dtype=np.int64), flags=np.asarray(ref.policy.flags, dtype=np.int8),
                         pieces=np.asarray(ref.policy.pieces, dtype=np.int64),
@@ -33,4 +35,4 @@ if __name__ == "__main__":
                         vocal_head=ref.vocal[: 4 * sec: 7].astype(np.float32), vocal_peak=np.float64(np.max(np.abs(ref.vocal))),
                         vad_segments=np.asarray([[s["start"], s["end"]] for s in ref.vad_segments], dtype=np.float64),
                         cache_rms=np.asarray(ref.cache.rms_series, dtype=np.float32), beat_times=np.asarray(ref.cache.beat_times, dtype=np.float64))
-    print("wrote tests/golden/c2_full_oracle.npz")
+    print(f"wrote tests/golden/{name}.npz")

@@ -342,16 +342,18 @@ def test_degenerate_tracks(hip_ctx, tmp_path):
         sp.split_track(np.zeros(0, np.float32))
 
 
-def test_c2_full_size_track_against_oracle_fixture(hip_ctx, golden_dir):
-    """BASELINE configs[1] at full size (4-min C2 song): the GPU path against the CPU oracle's committed result
-    (tests/golden/make_c2_full.py; the oracle needs minutes per run) - every guard boundary, every manifest cut, the
-    segment labels, pause cut points, VAD segments and beat grid exact; stems and RMS series within 1e-4."""
+@pytest.mark.parametrize("fixture,seconds,seed", [("c2_full_oracle", 240.0, 2), ("c2_150s_seed11_oracle", 150.0, 11)])
+def test_c2_full_size_track_against_oracle_fixture(hip_ctx, golden_dir, fixture, seconds, seed):
+    """BASELINE configs[1] at full size (4-min C2 song, and a second 150 s song of the same generator): the GPU path against
+    the CPU oracle's committed result (tests/golden/make_c2_full.py; the oracle needs minutes per run) - every guard
+    boundary, every manifest cut, the segment labels, pause cut points, VAD segments and beat grid exact; stems and RMS
+    series within 1e-4."""
     from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
     from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
     from audio_cut_amd.separation.backends import MDX23HipBackend
     from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
-    g = np.load(golden_dir / "c2_full_oracle.npz")
-    mix = signals.c2_song(240.0, seed=2)
+    g = np.load(golden_dir / f"{fixture}.npz")
+    mix = signals.c2_song(seconds, seed=seed)
     backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=0), ctx=hip_ctx, max_items_per_forward=32)
     backend.load_model()
     sp = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend))
