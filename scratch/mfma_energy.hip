@@ -11,6 +11,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 template <int LDS, int VALU, int GLD>
 __global__ __launch_bounds__(256, 2) void k_mix(const h8* __restrict__ src, const float4* __restrict__ big, float* __restrict__ sink, int iters) {
     __shared__ h8 s[3072];                                   // 48 KB
+    __shared__ float4 dma[4 * 16 * 64];                      // 64 KB landing zone of the LDS-DMA variants
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 3072; i += 256) s[i] = src[i & 4095];
     __syncthreads();
@@ -49,6 +50,20 @@ __global__ __launch_bounds__(256, 2) void k_mix(const h8* __restrict__ src, cons
 #pragma unroll
             for (int j = 0; j < 16; ++j) pre[j] = big[(gbase + (size_t)it * 4096 + j * 256) & ((1u << 17) - 1)];
         }
+        if (GLD == 3 && (it % 5) == 0) {                     // 8 register loads + 8 LDS-DMA loads (1 KB per wave-instruction), L2-resident
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pre[j] = big[(gbase + (size_t)it * 4096 + j * 256) & ((1u << 17) - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_global_load_lds(big + ((gbase + (size_t)it * 4096 + (8 + j) * 256) & ((1u << 17) - 1)),
+                                                 dma + ((tid >> 6) * 8 + j) * 64, 16, 0, 0);
+        }
+        if (GLD == 4 && (it % 5) == 0) {                     // 16 LDS-DMA loads, no register loads
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                __builtin_amdgcn_global_load_lds(big + ((gbase + (size_t)it * 4096 + j * 256) & ((1u << 17) - 1)),
+                                                 dma + ((tid >> 6) * 16 + j) * 64, 16, 0, 0);
+        }
         if (GLD == 2 && (it % 5) == 0) {                     // 16 coalesced loads, 4 of them streaming through 2 GiB (HBM), 12 L2-resident
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -70,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void k_mix(const h8* __restrict__ src, cons
                 }
             }
     }
+    if (GLD >= 3) { __syncthreads(); g.x += dma[tid].x + dma[tid + 2048].y; }
     float total = vs + g.x + g.y;
     for (int i = 0; i < 12; ++i) total += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (total == 123.456f) sink[0] = total;
@@ -106,6 +122,8 @@ int main(int argc, char** argv) {
         run<1, 0, 0>("MFMA + LDS fragment reads", d, big, sink, secs);
         run<0, 1, 0>("MFMA + split VALU", d, big, sink, secs);
         run<0, 0, 1>("MFMA + L2-resident loads", d, big, sink, secs);
+        run<0, 0, 3>("MFMA + 8 reg + 8 LDS-DMA loads (L2)", d, big, sink, secs);
+        run<0, 0, 4>("MFMA + 16 LDS-DMA loads (L2)", d, big, sink, secs);
         run<0, 0, 2>("MFMA + HBM streaming loads", d, big, sink, secs);
         run<1, 1, 1>("MFMA + LDS + VALU + L2 loads", d, big, sink, secs);
         run<1, 1, 2>("MFMA + LDS + VALU + HBM loads", d, big, sink, secs);
