@@ -8,7 +8,8 @@
 // Workgroup: 256 threads = 2 x 2 waves, tile 128 rows x (32 * NT) columns, wave tile 64 x (16 * NT) (NT = 6 or 3).
 // K is walked in stages of 32: the x tile is loaded as full 128-byte row segments (float4 per lane), split to f16
 // hi/lo once and staged in LDS as [row][k] with an 96-byte row stride (conflict-free ds_read_b128 A fragments); the
-// weights arrive pre-split and pre-packed in B-fragment order (conv_pack.pack_linear) and are copied through.  The
+// weights arrive pre-split and pre-packed in B-fragment order (conv_pack.pack_linear) and go global -> LDS by DMA
+// (global_load_lds_dwordx4, double-buffered, no registers).  The
 // next stage's global loads are issued before the current stage's MFMAs.  Epilogue: accumulators -> per-wave LDS
 // strip -> affine + ReLU (+ residual) -> 384-byte (192-byte for NT = 3) contiguous row stores.
 #include "ac_common.h"
@@ -35,11 +36,13 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     constexpr int OSTRIDE = 16 * NT + 4;              // floats per row of a wave's output strip
     constexpr int A_BYTES = 2 * GM_BM * GM_ASTRIDE * 2;
     constexpr int O_BYTES = 4 * 16 * OSTRIDE * 4;
-    constexpr int ARENA = (A_BYTES + BFRAGS * 16) > O_BYTES ? (A_BYTES + BFRAGS * 16) : O_BYTES;
+    // the weight fragments are double-buffered and filled by LDS-DMA one stage ahead (they are stored in LDS order already)
+    constexpr int ARENA = (A_BYTES + 2 * BFRAGS * 16) > O_BYTES ? (A_BYTES + 2 * BFRAGS * 16) : O_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[ARENA];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + GM_BM * GM_ASTRIDE;
-    f16x8* s_b = reinterpret_cast<f16x8*>(s_raw + A_BYTES);
+    f16x8* s_b0 = reinterpret_cast<f16x8*>(s_raw + A_BYTES);
+    f16x8* s_b1 = s_b0 + BFRAGS;
     float* s_out = reinterpret_cast<float*>(s_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,10 +77,13 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     const f16x8* wbase = wpk + (size_t)nb * n_stage * BFRAGS;
 
     float4 pre_a[GM_A_ITERS];
-    f16x8 pre_b[B_ITERS];
     auto prefetch = [&](int s) {
+        f16x8* dst = (s & 1) ? s_b1 : s_b0;
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) pre_b[i] = wbase[(size_t)s * BFRAGS + tid + 256 * i];
+        for (int i = 0; i < B_ITERS; ++i) {            // BFRAGS / 64 wave-instructions of 1 KB, B_ITERS per wave
+            const int inst = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds(wbase + (size_t)s * BFRAGS + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < GM_A_ITERS; ++i) pre_a[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)s * GM_BK);
     };
@@ -86,8 +92,7 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     prefetch(0);
     for (int s = 0; s < n_stage; ++s) {
         __syncthreads();                 // previous stage fully consumed
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) s_b[tid + 256 * i] = pre_b[i];
+        const f16x8* s_b = (s & 1) ? s_b1 : s_b0;
 #pragma unroll
         for (int i = 0; i < GM_A_ITERS; ++i) {
             const float v[4] = {pre_a[i].x, pre_a[i].y, pre_a[i].z, pre_a[i].w};
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
             *reinterpret_cast<uint2*>(&s_hi[a_off[i]]) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
             *reinterpret_cast<uint2*>(&s_lo[a_off[i]]) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
         }
+        __builtin_amdgcn_s_waitcnt(0);   // this stage's weight fragments have landed (issued before the x loads just consumed)
         __syncthreads();
         if (s + 1 < n_stage) prefetch(s + 1);
         f16x8 ah[GM_MT], al[GM_MT];
