@@ -49,11 +49,12 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     constexpr int OSTRIDE_UP = 48 + 4;                                       // up: strip [16 m][48 n]
     constexpr int OSTRIDE_DN = 64 + 4;                                       // down: strip [16 n][64 m]
     constexpr int O_BYTES = 4 * 16 * (MODE ? OSTRIDE_UP : OSTRIDE_DN) * 4;
-    constexpr int ARENA = (A_BYTES + RS_BFRAGS * 16) > O_BYTES ? (A_BYTES + RS_BFRAGS * 16) : O_BYTES;
+    constexpr int ARENA = (A_BYTES + 2 * RS_BFRAGS * 16) > O_BYTES ? (A_BYTES + 2 * RS_BFRAGS * 16) : O_BYTES;   // weights double-buffered (LDS-DMA)
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[ARENA];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + RS_BM * RS_ASTRIDE;
-    f16x8* s_b = reinterpret_cast<f16x8*>(s_raw + A_BYTES);
+    f16x8* s_b0 = reinterpret_cast<f16x8*>(s_raw + A_BYTES);
+    f16x8* s_b1 = s_b0 + RS_BFRAGS;
     float* s_out = reinterpret_cast<float*>(s_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,7 +82,6 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     // up:   item (pixel quad q = tid & 31, channel quad tid >> 5 of the stage's 8), four float4 = 4 pixels x 4 channels
     constexpr int A_LD = MODE ? 4 : 4;                       // float4 loads per thread per stage (both modes: 4)
     float4 pre_a[A_LD];
-    f16x8 pre_b[RS_B_ITERS];
     size_t dn_src[2];
     int dn_ci[2], dn_off[2];
     if (MODE == 0) {
@@ -100,8 +100,12 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     const f16x8* wbase = wpk + (size_t)nb * n_stage * RS_BFRAGS;
 
     auto prefetch = [&](int s) {
+        f16x8* dst = (s & 1) ? s_b1 : s_b0;         // weight fragments: global -> LDS by DMA, 1 KB per wave-instruction, one stage ahead
 #pragma unroll
-        for (int i = 0; i < RS_B_ITERS; ++i) pre_b[i] = wbase[(size_t)s * RS_BFRAGS + tid + 256 * i];
+        for (int i = 0; i < RS_B_ITERS; ++i) {
+            const int inst = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds(wbase + (size_t)s * RS_BFRAGS + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
+        }
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -119,8 +123,6 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
         }
     };
     auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < RS_B_ITERS; ++i) s_b[tid + 256 * i] = pre_b[i];
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -142,8 +144,10 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     for (int s = 0; s < n_stage; ++s) {
         __syncthreads();
         commit();
+        __builtin_amdgcn_s_waitcnt(0);       // this stage's weight fragments have landed
         __syncthreads();
         if (s + 1 < n_stage) prefetch(s + 1);
+        const f16x8* s_b = (s & 1) ? s_b1 : s_b0;
         f16x8 ah[RS_MT], al[RS_MT];
 #pragma unroll
         for (int m = 0; m < RS_MT; ++m) {

@@ -57,6 +57,64 @@ def cpu_baseline(sample_s: float, weights, spec) -> dict:
             "n_boundaries": len(res.sample_boundaries)}
 
 
+class SocketSampler:
+    """Power cap, and power draw / shader clock sampled every 50 ms from the amdgpu hwmon node while the timed region runs
+    (a side thread reading three sysfs files).  The U-Net kernels run on the package power cap: boxes of the
+    pool that hold different clocks under it give different `value`s, and this block says which kind the run was on."""
+
+    def __init__(self, device_index: int = 0) -> None:
+        import glob
+        import threading
+        nodes = []
+        try:                                   # the hwmon node of the PCI function torch's device sits on
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            nodes = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*"))
+            self.pci = bdf
+        except Exception:
+            self.pci = None
+        if not nodes:
+            nodes = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.hw = nodes[0] if nodes else None
+        self.samples: list = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+
+    def _read(self, name: str):
+        try:
+            with open(f"{self.hw}/{name}") as fh:
+                return int(fh.read().strip())
+        except Exception:
+            return None
+
+    def _loop(self) -> None:
+        while not self._stop.wait(0.05):
+            p = self._read("power1_average") or self._read("power1_input")
+            f = self._read("freq1_input")
+            if p is not None or f is not None:
+                self.samples.append((p, f))
+
+    def start(self) -> "SocketSampler":
+        if self.hw:
+            self._thread.start()
+        return self
+
+    def stop(self) -> dict:
+        if not self.hw:
+            return {}
+        self._stop.set()
+        self._thread.join(timeout=1.0)
+        cap = self._read("power1_cap")
+        pw = sorted(p / 1e6 for p, _ in self.samples if p)
+        fr = sorted(f / 1e6 for _, f in self.samples if f)
+        out = {"pci": self.pci, "power_cap_w": cap / 1e6 if cap else None, "samples": len(self.samples)}
+        if pw:
+            out["power_w_median"] = round(pw[len(pw) // 2], 1)
+        if fr:
+            out["sclk_mhz_median"] = round(fr[len(fr) // 2], 1)
+        return out
+
+
 DOMINANT = "k_conv3x3_f16x3"           # audio_cut_amd/csrc/ac_conv.hip; rocprofv3 prints it as `void k_conv3x3_f16x3<true>(...)`
 F16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_16x16x32_f16)
 # MFMA FLOPs the split issues per algorithmic FLOP: 3 products (hi*hi + hi*lo + lo*hi); tap 8 of two consecutive 16-channel
@@ -206,10 +264,12 @@ def main() -> None:
     phases = {"separate_s": 0.0, "detect_s": 0.0, "finalize_s": 0.0}
     policy_s = 0.0
     summaries = []
+    sampler = SocketSampler(dev_index).start() if rank == 0 else None
     t0 = time.perf_counter()
     step_results = pipeline.run([job] * args.steps)              # exactly K steps (tracks), `depth` of them in flight
     torch.cuda.synchronize()
     t_done = time.perf_counter()
+    socket_state = sampler.stop() if sampler else {}
     for step, res in enumerate(step_results):
         ts = t0
         st = res["gpu_meta"].get("gpu_pipeline_stage_ms", {})
@@ -274,6 +334,7 @@ def main() -> None:
             out["framewise_rooflines"] = framewise_rooflines(hip, mix_dev)
         if world == 1 and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds, weights, spec)
+        out["socket_under_load"] = socket_state
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
