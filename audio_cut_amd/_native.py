@@ -77,6 +77,7 @@ SIGNATURES = {
     "ac_space_to_depth2x": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_depth_to_space2x_bias_relu_mul": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
+    "ac_conv3x3_f16x3_w96": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_conv3x3_f16x3_first": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P]),
     "ac_conv1x1_small": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I64, _I, _P]),
@@ -140,6 +141,8 @@ class Context:
         self._h = handle
         # 3x3 convs of the U-Net: "f16x3" = ac_conv3x3_f16x3 (f16 MFMA, 3-term hi/lo split), "miopen" = PyTorch/MIOpen float32
         self.conv_impl = os.environ.get("AUDIOCUT_CONV_IMPL", "f16x3")
+        # layers with C_in % 32 == 0 and C_out % 96 == 0 use the 96-channel-per-workgroup kernel (ac_conv3x3_f16x3_w96) unless disabled
+        self.conv_wide = os.environ.get("AUDIOCUT_CONV_WIDE", "1") != "0"
         # TDF layers: "f16x3" = ac_tdf_linear_f16x3 (fused GEMM + affine + ReLU (+ residual)), "rocblas" = float32 rocBLAS + epilogues
         self.tdf_impl = os.environ.get("AUDIOCUT_TDF_IMPL", "f16x3")
         # the graph's first 1x1 conv is generated inside the first 3x3 conv's loader (ac_conv3x3_f16x3_first) unless disabled
@@ -559,6 +562,18 @@ class Context:
             out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
         _check(self.lib.ac_conv3x3_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
                                          float(w_unscale), int(relu), _stream()))
+        return out
+
+    def conv3x3_f16x3_w96(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
+                          relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """conv3x3_f16x3 with 96 output channels per workgroup (C_in % 32 == 0, C_out % 96 == 0; `pack_conv3x3_w96` weights)."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("conv3x3_f16x3_w96 expects a contiguous float32 NCHW tensor")
+        b, c_in, h, w = x.shape
+        if out is None:
+            out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_conv3x3_f16x3_w96(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
+                                             float(w_unscale), int(relu), _stream()))
         return out
 
     def conv3x3_f16x3_first(self, spec: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,

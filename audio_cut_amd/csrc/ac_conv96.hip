@@ -1,0 +1,223 @@
+// 3x3 convolution, 96 output channels per workgroup: the wide-tile sibling of ac_conv.hip for layers with C_in % 32 == 0 and
+// C_out % 96 == 0 (levels 1, 3, 5 of the U-Net: C = 96, 192, 288).  Same arithmetic (3-term float16 split, float32 accumulate in
+// v_mfma_f32_16x16x32_f16), same 8 x 32 pixel tile and 4 waves, but every staged activation byte and every activation fragment
+// read from LDS now feeds twice as many MFMAs - under the package power cap the loads / LDS reads / VALU split around the
+// MFMAs are what the time goes to.
+//
+// LDS is what bounds a workgroup (two per CU), so K is walked in stages of 8 input channels:
+//   patch   [10 rows][50-pixel row stride][8 ch] f16, hi and lo: 2 x 8,000 B      (40 columns staged, stride 50: see below)
+//   weights two DMA-filled buffers: even stages 24 KB (two k-steps x (hi, lo) x 6 row tiles x 1 KB), odd stages 36 KB
+//   total   77,440 B  -> 154,880 B for two workgroups
+// A k-step of 32 is 4 taps x 8 channels (lane group g carries tap 4 ks + g).  Taps 0..7 are two k-steps per stage; tap 8
+// of FOUR consecutive stages shares one k-step: stage cb loads its tap-8 fragments into lane group cb & 3 of registers that
+// live across the stages, and the stage with cb & 3 == 3 issues it (its weights sit behind that stage's own two k-steps in
+// the odd buffer).  32 channels therefore cost 9 k-steps, none padded.
+// Bank layout: a pixel is 16 B, so the 16 pixels of one tap are 256 contiguous bytes = all 64 banks once.  ds_read_b128 serves
+// lanes {0-3,12-15,20-27} together: two lane groups whose taps sit in one row differ by one pixel and never collide; the
+// pairs that straddle rows (taps 2|3) need the row stride to be 2 pixels mod 16 -> 50 pixels.
+#include "ac_common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define W9_TH 8
+#define W9_TW 32
+#define W9_PH (W9_TH + 2)
+#define W9_LW 40                 // staged columns per patch row: the 10 aligned float4 of a row, x0 - 4 .. x0 + 35
+#define W9_RS 50                 // LDS row stride in pixels
+#define W9_CB 8                  // input channels per stage
+#define W9_COB 96
+#define W9_MT 6
+#define W9_KFR (2 * W9_MT * 64)                      // 768 16-byte fragments per k-step (hi, lo)
+#define W9_PATCH_BYTES (2 * W9_PH * W9_RS * W9_CB * 2)
+#define W9_OUT_STRIDE (W9_TW + 4)
+
+__device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_w96(const float* __restrict__ x, const f16x8* __restrict__ wpk,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int C_in, int C_out, int H, int W, float w_unscale, int bw) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[W9_PATCH_BYTES + (2 + 3) * W9_KFR * 16];
+    unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
+    unsigned short* s_lo = s_hi + W9_PH * W9_RS * W9_CB;
+    f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw + W9_PATCH_BYTES);           // even stages: 2 k-steps
+    f16x8* s_w1 = s_w0 + 2 * W9_KFR;                                           // odd stages: 2 k-steps (+ the shared tap-8 step)
+    float* s_out = reinterpret_cast<float*>(s_raw);                           // [48 co][8 rows][36] = 55,296 B, two passes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_cob = C_out / W9_COB;
+    const int tiles_x = W / W9_TW, tiles_y = H / W9_TH;
+    int wi = blockIdx.x;                                                       // XCD-aware order as in ac_conv.hip
+    if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int cob = wi % n_cob;
+    int t = wi / n_cob;
+    const int b = t / (tiles_x * tiles_y);
+    t -= b * (tiles_x * tiles_y);
+    const int band = t / (tiles_y * bw);
+    t -= band * (tiles_y * bw);
+    const int y0 = (t / bw) * W9_TH, x0 = (band * bw + t % bw) * W9_TW;
+    const int n_cb = C_in / W9_CB;                                             // multiple of 4
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * C_in * plane;
+
+    f32x4 acc[W9_MT][4];
+#pragma unroll
+    for (int m = 0; m < W9_MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 k8h[4], k8l[4];               // tap-8 activation fragments of four consecutive stages, one lane group each
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { k8h[q] = (f16x8)(_Float16)0; k8l[q] = (f16x8)(_Float16)0; }
+
+    const int g = lane >> 4, px = lane & 15;
+    // fragments per stage in the packed weights: [cob][cb][3 k-steps][2][6][64]; the third k-step exists for cb & 3 == 3 only
+    const f16x8* wbase = wpk + (size_t)cob * n_cb * 3 * W9_KFR;
+
+    // staging: thread -> (row 0..9, column quad 0..9, channel quad 0..1): one aligned float4 (4 pixels) of 4 channels each
+    const int a_c4 = tid & 1, a_rest = tid >> 1;
+    const int a_row = a_rest / 10, a_qd = a_rest - a_row * 10;
+    const bool a_live = a_rest < W9_PH * 10;
+    int a_src = -1;
+    const int a_off = ((a_row * W9_RS + 4 * a_qd) * W9_CB + a_c4 * 4);         // u16 elements
+    if (a_live) {
+        const int gy = y0 + a_row - 1, gx = x0 - 4 + 4 * a_qd;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_src = gy * W + gx;
+    }
+    float4 pre_x[4];
+
+    auto prefetch = [&](int cb) {
+        const f16x8* wcb = wbase + (size_t)cb * 3 * W9_KFR;
+        f16x8* dst = (cb & 1) ? s_w1 : s_w0;
+        const int n_inst = ((cb & 3) == 3) ? 3 * W9_KFR / 64 : 2 * W9_KFR / 64;      // 36 or 24 wave-instructions of 1 KB
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int inst = wave + 4 * i;
+            if (inst < n_inst) __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = cb * W9_CB + a_c4 * 4 + q;
+            pre_x[q] = (a_src >= 0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    prefetch(0);
+    for (int cb = 0; cb < n_cb; ++cb) {
+        __syncthreads();                 // previous stage fully consumed
+        if (a_live) {
+            const float* v4[4] = {&pre_x[0].x, &pre_x[1].x, &pre_x[2].x, &pre_x[3].x};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned short h4[4], l4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fminf(fmaxf(v4[q][k], -65504.f), 65504.f);
+                    const _Float16 hv = (_Float16)v;
+                    h4[q] = w9_bits(hv);
+                    l4[q] = w9_bits((_Float16)(v - (float)hv));
+                }
+                const int off = a_off + k * W9_CB;
+                *reinterpret_cast<uint2*>(&s_hi[off]) = make_uint2((unsigned)h4[0] | ((unsigned)h4[1] << 16), (unsigned)h4[2] | ((unsigned)h4[3] << 16));
+                *reinterpret_cast<uint2*>(&s_lo[off]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // this stage's weight fragments have landed
+        __syncthreads();
+        if (cb + 1 < n_cb) prefetch(cb + 1);
+        const f16x8* s_w = (cb & 1) ? s_w1 : s_w0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int tap = 4 * ks + g;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+                const int off = ((ty + dy) * W9_RS + tx + dx + 3) * W9_CB;           // patch column c is staged column c + 3
+                bh[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+                bl[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+            }
+#pragma unroll
+            for (int m = 0; m < W9_MT; ++m) {
+                const f16x8 ah = s_w[((ks * 2 + 0) * W9_MT + m) * 64 + lane];
+                const f16x8 al = s_w[((ks * 2 + 1) * W9_MT + m) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[q], acc[m][q], 0, 0, 0);
+                }
+            }
+        }
+        // tap 8 (dy = dx = 2) of this stage goes into lane group cb & 3 of the carried fragments
+        if (g == (cb & 3)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+                const int off = ((ty + 2) * W9_RS + tx + 2 + 3) * W9_CB;
+                k8h[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+                k8l[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+            }
+        }
+        if ((cb & 3) == 3) {
+#pragma unroll
+            for (int m = 0; m < W9_MT; ++m) {
+                const f16x8 ah = s_w[((2 * 2 + 0) * W9_MT + m) * 64 + lane];
+                const f16x8 al = s_w[((2 * 2 + 1) * W9_MT + m) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, k8l[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, k8h[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, k8h[q], acc[m][q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue in two passes of 48 output channels through the LDS tile [co][row][x] -> 128-byte row stores
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                 // stage buffers (pass 0) / the previous pass's tile (pass 1) are done with
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm) {
+            const int m = pass * 3 + mm;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mm * 16 + g * 4 + r;
+                    float v = acc[m][q][r] * w_unscale + bias[cob * W9_COB + pass * 48 + co];
+                    if (RELU) v = fmaxf(v, 0.f);
+                    s_out[(co * W9_TH + ty) * W9_OUT_STRIDE + tx] = v;
+                }
+            }
+        }
+        __syncthreads();
+        float* ob = out + ((size_t)b * C_out + (size_t)cob * W9_COB + pass * 48) * plane;
+        for (int e = tid; e < 48 * W9_TH * (W9_TW / 4); e += 256) {
+            const int line = e >> 3, q4 = e & 7;
+            const int co = line >> 3, ty = line & 7;
+            const float4 v = *reinterpret_cast<const float4*>(&s_out[line * W9_OUT_STRIDE + 4 * q4]);
+            *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
+        }
+    }
+}
+
+extern "C" int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                                     int C_out, int H, int W, float w_unscale, int relu, void* stream) {
+    AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
+    AC_REQUIRE(B > 0 && C_in > 0 && C_in % 32 == 0 && C_out > 0 && C_out % W9_COB == 0, "C_in % 32 == 0 and C_out % 96 == 0");
+    AC_REQUIRE(H > 0 && H % W9_TH == 0 && W > 0 && W % W9_TW == 0, "H % 8 == 0 and W % 32 == 0");
+    AC_REQUIRE((long long)H * W < (1LL << 31), "plane too large");
+    const long long nblk = (long long)B * (C_out / W9_COB) * (H / W9_TH) * (W / W9_TW);
+    AC_REQUIRE(nblk < (1LL << 31), "grid too large");
+    const int tiles_x = W / W9_TW;
+    const int bw = tiles_x % 4 == 0 ? 4 : (tiles_x % 3 == 0 ? 3 : (tiles_x % 2 == 0 ? 2 : 1));
+    dim3 grid((unsigned)nblk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const f16x8* wp = (const f16x8*)w_packed;
+    if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+    else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

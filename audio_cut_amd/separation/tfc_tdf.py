@@ -254,8 +254,9 @@ class _Block(nn.Module):
             self.register_buffer(f"lb{j}", torch.from_numpy(sh.astype(np.float32)).view(1, -1, 1, 1))
 
     def pack_for_hip(self) -> None:
-        """f16 hi/lo fragment-ordered copies of the folded 3x3 weights for ac_conv3x3_f16x3."""
-        from .conv_pack import pack_conv3x3, pack_linear
+        """f16 hi/lo fragment-ordered copies of the folded 3x3 weights for ac_conv3x3_f16x3 (and, where the shape allows
+        96 output channels per workgroup, for ac_conv3x3_f16x3_w96)."""
+        from .conv_pack import conv3x3_wide_tileable, pack_conv3x3, pack_conv3x3_w96, pack_linear
         self._l_unscale = [None, None]
         for j in range(2):
             w = getattr(self, f"lw{j}").detach().cpu().numpy()
@@ -269,6 +270,9 @@ class _Block(nn.Module):
             packed, unscale = pack_conv3x3(w)
             self._w_unscale.append(unscale)
             self.register_buffer(f"cwp{j}", torch.from_numpy(packed.view(np.int16)).to(getattr(self, f"cw{j}").device))
+            if conv3x3_wide_tileable(w.shape[0], w.shape[1]):          # same power-of-two scale: `unscale` holds for both layouts
+                wide, _ = pack_conv3x3_w96(w)
+                self.register_buffer(f"cwq{j}", torch.from_numpy(wide.view(np.int16)).to(getattr(self, f"cw{j}").device))
 
     def _conv(self, x: torch.Tensor, j: int, hip, probe):
         """3x3 conv + bias + ReLU.  `hip.conv_impl == "f16x3"`: one fused HIP kernel on the f16 matrix cores (3-term
@@ -278,7 +282,9 @@ class _Block(nn.Module):
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        if use_mfma:
+        if use_mfma and hasattr(self, f"cwq{j}") and getattr(hip, "conv_wide", True):
+            y = hip.conv3x3_f16x3_w96(x, getattr(self, f"cwq{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
+        elif use_mfma:
             y = hip.conv3x3_f16x3(x, getattr(self, f"cwp{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
         else:
             y = F.conv2d(x, getattr(self, f"cw{j}"), None, padding=self.pad)

@@ -82,6 +82,33 @@ def test_conv3x3_f16x3_kernel(hip_ctx):
         assert float((got - edge).abs().max() / edge.abs().max()) < 2e-6
 
 
+def test_conv3x3_f16x3_w96_kernel(hip_ctx):
+    """ac_conv3x3_f16x3_w96 (96 output channels per workgroup, 8-channel stages, tap 8 shared by four stages) against a
+    float64 convolution: the U-Net level shapes it serves, a rectangular C_in != C_out case, one tile, and the borders."""
+    import torch.nn.functional as F
+    from audio_cut_amd.separation.conv_pack import conv3x3_wide_tileable, pack_conv3x3_w96
+    g = torch.Generator().manual_seed(5)
+    dev = hip_ctx.device
+    for ci, co, h, w_ in ((96, 96, 128, 1536), (192, 192, 32, 384), (288, 288, 8, 96), (32, 96, 8, 32), (64, 192, 24, 96)):
+        assert conv3x3_wide_tileable(co, ci)
+        x = (torch.randn(2, ci, h, w_, generator=g) * 2).to(dev)
+        wt = torch.randn(co, ci, 3, 3, generator=g) / np.sqrt(9 * ci)
+        b = torch.randn(co, generator=g) * 0.1
+        packed, unscale = pack_conv3x3_w96(wt.numpy())
+        wp = torch.from_numpy(packed.view(np.int16)).to(dev)
+        full = F.conv2d(x.double().cpu(), wt.double(), b.double(), padding=1)
+        for relu in (True, False):
+            y = hip_ctx.conv3x3_f16x3_w96(x, wp, b.to(dev), co, unscale, relu=relu).double().cpu()
+            ref = F.relu(full) if relu else full
+            assert float((y - ref).abs().max() / ref.abs().max()) < 2e-6, (ci, co, relu)
+            if not relu:
+                edges = [y[:, :, [0, -1], :] - full[:, :, [0, -1], :], y[:, :, :, [0, -1]] - full[:, :, :, [0, -1]]]
+                assert max(float(e.abs().max()) for e in edges) / float(full.abs().max()) < 2e-6
+    assert not conv3x3_wide_tileable(144, 144) and not conv3x3_wide_tileable(96, 48)
+    with pytest.raises(Exception):
+        hip_ctx.conv3x3_f16x3_w96(torch.zeros(1, 48, 8, 32, device=dev), wp, b.to(dev), 96, 1.0)
+
+
 def test_tdf_linear_f16x3_kernel(hip_ctx):
     """ac_tdf_linear_f16x3 (GEMM + per-channel affine + ReLU (+ residual)) against float64 on the U-Net's TDF shapes."""
     import torch.nn.functional as F
