@@ -78,6 +78,7 @@ SIGNATURES = {
     "ac_depth_to_space2x_bias_relu_mul": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_conv3x3_f16x3_w96": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
+    "ac_conv3x3_f16x3_s8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_conv3x3_f16x3_first": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P]),
     "ac_conv1x1_small": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I64, _I, _P]),
@@ -141,7 +142,7 @@ class Context:
         self._h = handle
         # 3x3 convs of the U-Net: "f16x3" = ac_conv3x3_f16x3 (f16 MFMA, 3-term hi/lo split), "miopen" = PyTorch/MIOpen float32
         self.conv_impl = os.environ.get("AUDIOCUT_CONV_IMPL", "f16x3")
-        # layers with C_in % 32 == 0 and C_out % 96 == 0 use the 96-channel-per-workgroup kernel (ac_conv3x3_f16x3_w96) unless disabled
+        # the 8-channel-stage conv kernels (ac_conv3x3_f16x3_w96 where C_out % 96 == 0, else ac_conv3x3_f16x3_s8) unless disabled
         self.conv_wide = os.environ.get("AUDIOCUT_CONV_WIDE", "1") != "0"
         # TDF layers: "f16x3" = ac_tdf_linear_f16x3 (fused GEMM + affine + ReLU (+ residual)), "rocblas" = float32 rocBLAS + epilogues
         self.tdf_impl = os.environ.get("AUDIOCUT_TDF_IMPL", "f16x3")
@@ -574,6 +575,18 @@ class Context:
             out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
         _check(self.lib.ac_conv3x3_f16x3_w96(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
                                              float(w_unscale), int(relu), _stream()))
+        return out
+
+    def conv3x3_f16x3_s8(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
+                         relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The 8-channel-stage conv kernel with 48 output channels per workgroup (`pack_conv3x3_w96(w, cob=48)` weights)."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("conv3x3_f16x3_s8 expects a contiguous float32 NCHW tensor")
+        b, c_in, h, w = x.shape
+        if out is None:
+            out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
+        _check(self.lib.ac_conv3x3_f16x3_s8(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
+                                            float(w_unscale), int(relu), _stream()))
         return out
 
     def conv3x3_f16x3_first(self, spec: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,

@@ -26,24 +26,27 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define W9_LW 40                 // staged columns per patch row: the 10 aligned float4 of a row, x0 - 4 .. x0 + 35
 #define W9_RS 50                 // LDS row stride in pixels
 #define W9_CB 8                  // input channels per stage
-#define W9_COB 96
-#define W9_MT 6
-#define W9_KFR (2 * W9_MT * 64)                      // 768 16-byte fragments per k-step (hi, lo)
 #define W9_PATCH_BYTES (2 * W9_PH * W9_RS * W9_CB * 2)
 #define W9_OUT_STRIDE (W9_TW + 4)
 
 __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
-template <bool RELU>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_w96(const float* __restrict__ x, const f16x8* __restrict__ wpk,
+// MT = 16-row output-channel tiles per workgroup: 6 (96 channels, two workgroups per CU) or 3 (48 channels, three per CU).
+template <int MT, int OCC, bool RELU>
+__global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int C_in, int C_out, int H, int W, float w_unscale, int bw) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[W9_PATCH_BYTES + (2 + 3) * W9_KFR * 16];
+    constexpr int W9_MT = MT, W9_COB = 16 * MT;
+    constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
+    constexpr int EP_M = (MT == 6) ? 3 : 2;                   // row tiles per epilogue pass (the output tile must fit the arena)
+    constexpr int EP_BYTES = EP_M * 16 * W9_TH * W9_OUT_STRIDE * 4;
+    constexpr int K_BYTES = W9_PATCH_BYTES + (2 + 3) * W9_KFR * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[K_BYTES > EP_BYTES ? K_BYTES : EP_BYTES];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + W9_PH * W9_RS * W9_CB;
     f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw + W9_PATCH_BYTES);           // even stages: 2 k-steps
     f16x8* s_w1 = s_w0 + 2 * W9_KFR;                                           // odd stages: 2 k-steps (+ the shared tap-8 step)
-    float* s_out = reinterpret_cast<float*>(s_raw);                           // [48 co][8 rows][36] = 55,296 B, two passes
+    float* s_out = reinterpret_cast<float*>(s_raw);                           // [16 EP_M co][8 rows][36], MT / EP_M passes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_cob = C_out / W9_COB;
     const int tiles_x = W / W9_TW, tiles_y = H / W9_TH;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_w96(const float* __res
     const int band = t / (tiles_y * bw);
     t -= band * (tiles_y * bw);
     const int y0 = (t / bw) * W9_TH, x0 = (band * bw + t % bw) * W9_TW;
-    const int n_cb = C_in / W9_CB;                                             // multiple of 4
+    const int n_cb = C_in / W9_CB;                                             // even: the stage that issues a shared step is always odd
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * C_in * plane;
 
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_w96(const float* __res
     auto prefetch = [&](int cb) {
         const f16x8* wcb = wbase + (size_t)cb * 3 * W9_KFR;
         f16x8* dst = (cb & 1) ? s_w1 : s_w0;
-        const int n_inst = ((cb & 3) == 3) ? 3 * W9_KFR / 64 : 2 * W9_KFR / 64;      // 36 or 24 wave-instructions of 1 KB
+        const bool third = ((cb & 3) == 3) || cb == n_cb - 1;                       // this stage carries the shared tap-8 k-step
+        const int n_inst = third ? 3 * W9_KFR / 64 : 2 * W9_KFR / 64;                // wave-instructions of 1 KB
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int inst = wave + 4 * i;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_w96(const float* __res
                 k8l[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
             }
         }
-        if ((cb & 3) == 3) {
+        if ((cb & 3) == 3 || cb == n_cb - 1) {           // a trailing group of two stages: lane groups 2-3 meet zero weights
 #pragma unroll
             for (int m = 0; m < W9_MT; ++m) {
                 const f16x8 ah = s_w[((2 * 2 + 0) * W9_MT + m) * 64 + lane];
@@ -173,28 +177,31 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_w96(const float* __res
             }
         }
     }
-    // ---- epilogue in two passes of 48 output channels through the LDS tile [co][row][x] -> 128-byte row stores
+    // ---- epilogue in passes of EP_M row tiles through the LDS tile [co][row][x] -> 128-byte row stores
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();                 // stage buffers (pass 0) / the previous pass's tile (pass 1) are done with
+    for (int m0 = 0; m0 < W9_MT; m0 += EP_M) {
+        const int n_m = (W9_MT - m0) < EP_M ? (W9_MT - m0) : EP_M;
+        __syncthreads();                 // stage buffers (first pass) / the previous pass's tile are done with
 #pragma unroll
-        for (int mm = 0; mm < 3; ++mm) {
-            const int m = pass * 3 + mm;
+        for (int mm = 0; mm < EP_M; ++mm) {
+            if (mm < n_m) {
+                const int m = m0 + mm;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+                for (int q = 0; q < 4; ++q) {
+                    const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = mm * 16 + g * 4 + r;
-                    float v = acc[m][q][r] * w_unscale + bias[cob * W9_COB + pass * 48 + co];
-                    if (RELU) v = fmaxf(v, 0.f);
-                    s_out[(co * W9_TH + ty) * W9_OUT_STRIDE + tx] = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = mm * 16 + g * 4 + r;
+                        float v = acc[m][q][r] * w_unscale + bias[cob * W9_COB + m0 * 16 + co];
+                        if (RELU) v = fmaxf(v, 0.f);
+                        s_out[(co * W9_TH + ty) * W9_OUT_STRIDE + tx] = v;
+                    }
                 }
             }
         }
         __syncthreads();
-        float* ob = out + ((size_t)b * C_out + (size_t)cob * W9_COB + pass * 48) * plane;
-        for (int e = tid; e < 48 * W9_TH * (W9_TW / 4); e += 256) {
+        float* ob = out + ((size_t)b * C_out + (size_t)cob * W9_COB + m0 * 16) * plane;
+        for (int e = tid; e < n_m * 16 * W9_TH * (W9_TW / 4); e += 256) {
             const int line = e >> 3, q4 = e & 7;
             const int co = line >> 3, ty = line & 7;
             const float4 v = *reinterpret_cast<const float4*>(&s_out[line * W9_OUT_STRIDE + 4 * q4]);
@@ -203,21 +210,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_w96(const float* __res
     }
 }
 
-extern "C" int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                                     int C_out, int H, int W, float w_unscale, int relu, void* stream) {
+static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
+                     int H, int W, float w_unscale, int relu, void* stream, int cob_width) {
     AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
-    AC_REQUIRE(B > 0 && C_in > 0 && C_in % 32 == 0 && C_out > 0 && C_out % W9_COB == 0, "C_in % 32 == 0 and C_out % 96 == 0");
+    AC_REQUIRE(B > 0 && C_in > 0 && C_in % 16 == 0 && C_out > 0 && C_out % cob_width == 0, "C_in % 16 == 0 and C_out % (96 or 48) == 0");
     AC_REQUIRE(H > 0 && H % W9_TH == 0 && W > 0 && W % W9_TW == 0, "H % 8 == 0 and W % 32 == 0");
     AC_REQUIRE((long long)H * W < (1LL << 31), "plane too large");
-    const long long nblk = (long long)B * (C_out / W9_COB) * (H / W9_TH) * (W / W9_TW);
+    const long long nblk = (long long)B * (C_out / cob_width) * (H / W9_TH) * (W / W9_TW);
     AC_REQUIRE(nblk < (1LL << 31), "grid too large");
     const int tiles_x = W / W9_TW;
     const int bw = tiles_x % 4 == 0 ? 4 : (tiles_x % 3 == 0 ? 3 : (tiles_x % 2 == 0 ? 2 : 1));
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
     const f16x8* wp = (const f16x8*)w_packed;
-    if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
-    else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+    if (cob_width == 96) {
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+    } else {
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+    }
     AC_LAUNCH_CHECK();
     return AC_OK;
+}
+
+extern "C" int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                                     int C_out, int H, int W, float w_unscale, int relu, void* stream) {
+    return w9_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, 96);
+}
+
+extern "C" int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                                    int C_out, int H, int W, float w_unscale, int relu, void* stream) {
+    return w9_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, 48);
 }

@@ -70,33 +70,38 @@ def pack_conv3x3(weight: np.ndarray) -> Tuple[np.ndarray, float]:
 
 
 def conv3x3_wide_tileable(c_out: int, c_in: int) -> bool:
-    """shapes `ac_conv3x3_f16x3_w96` takes (96 output channels per workgroup, 8-channel stages, tap 8 shared by 4 stages)."""
-    return c_out % 96 == 0 and c_in % 32 == 0
+    """shapes `ac_conv3x3_f16x3_w96` takes (96 output channels per workgroup, 8-channel stages, tap 8 shared by up to 4 stages)."""
+    return c_out % 96 == 0 and c_in % 16 == 0
 
 
-def pack_conv3x3_w96(weight: np.ndarray) -> Tuple[np.ndarray, float]:
-    """Weights for `ac_conv3x3_f16x3_w96` (csrc/ac_conv96.hip): K walks stages of 8 input channels; a k-step of 32 is 4 taps x
-    8 channels (lane group g: tap 4 ks + g, ks = 0, 1); the third k-step of a stage with cb % 4 == 3 carries tap 8 of the
-    stages cb - 3 + g (all-zero and never loaded for the other stages).
-    Result: (uint16 [C_out/96][C_in/8][3][2 (hi, lo)][6 (row tiles)][64 lanes][8], w_unscale)."""
+def pack_conv3x3_w96(weight: np.ndarray, cob: int = 96) -> Tuple[np.ndarray, float]:
+    """Weights for `ac_conv3x3_f16x3_w96` (cob = 96) / `ac_conv3x3_f16x3_s8` (cob = 48) (csrc/ac_conv96.hip): K walks stages
+    of 8 input channels; a k-step of 32 is 4 taps x 8 channels (lane group g: tap 4 ks + g, ks = 0, 1); the third k-step of a
+    stage with cb % 4 == 3 carries tap 8 of the stages cb - 3 + g, and the last stage of a trailing group of two (C_in % 32 == 16)
+    carries tap 8 of the stages cb - 1 + g in lane groups 0-1 against zeros in 2-3 (all-zero and never loaded elsewhere).
+    Result: (uint16 [C_out/cob][C_in/8][3][2 (hi, lo)][cob/16 (row tiles)][64 lanes][8], w_unscale)."""
     co, ci, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or not conv3x3_wide_tileable(co, ci):
-        raise ValueError("pack_conv3x3_w96 needs [C_out % 96 == 0, C_in % 32 == 0, 3, 3]")
+    if (kh, kw) != (3, 3) or cob not in (48, 96) or co % cob or ci % 16:
+        raise ValueError("pack_conv3x3_w96 needs [C_out % cob == 0, C_in % 16 == 0, 3, 3], cob 96 or 48")
     scale = weight_scale(weight)
     hi, lo = split_hi_lo(np.asarray(weight, dtype=np.float32) * np.float32(scale))
-    taps = np.stack([hi.view(np.uint16).reshape(co, ci, 9), lo.view(np.uint16).reshape(co, ci, 9)])      # [2][co][ci][9]
+    taps = np.zeros((2, co, ci + 8, 9), dtype=np.uint16)                                                 # channels ci.. = zeros
+    taps[0, :, :ci] = hi.view(np.uint16).reshape(co, ci, 9)
+    taps[1, :, :ci] = lo.view(np.uint16).reshape(co, ci, 9)
     lane = np.arange(64)
     r, g, j = lane & 15, lane >> 4, np.arange(8)
-    out = np.zeros((co // 96, ci // 8, 3, 2, 6, 64, 8), dtype=np.uint16)
-    for cob in range(co // 96):
-        for mt in range(6):
-            rows = (cob * 96 + mt * 16 + r)[:, None]
-            for cb in range(ci // 8):
+    n_cb, mt_n = ci // 8, cob // 16
+    out = np.zeros((co // cob, n_cb, 3, 2, mt_n, 64, 8), dtype=np.uint16)
+    for blk in range(co // cob):
+        for mt in range(mt_n):
+            rows = (blk * cob + mt * 16 + r)[:, None]
+            for cb in range(n_cb):
                 own = cb * 8 + j[None, :] + 0 * g[:, None]                                                # [64, 8]
                 for ks in range(2):
-                    out[cob, cb, ks, :, mt] = taps[:, rows, own, (4 * ks + g)[:, None]]
-                if cb % 4 == 3:
-                    out[cob, cb, 2, :, mt] = taps[:, rows, (cb - 3 + g)[:, None] * 8 + j[None, :], 8]
+                    out[blk, cb, ks, :, mt] = taps[:, rows, own, (4 * ks + g)[:, None]]
+                if cb % 4 == 3 or cb == n_cb - 1:
+                    stage = np.where(g <= cb % 4, cb - cb % 4 + g, n_cb)                                  # n_cb -> the zero channels
+                    out[blk, cb, 2, :, mt] = taps[:, rows, stage[:, None] * 8 + j[None, :], 8]
     return out, 1.0 / scale
 
 

@@ -270,9 +270,14 @@ class _Block(nn.Module):
             packed, unscale = pack_conv3x3(w)
             self._w_unscale.append(unscale)
             self.register_buffer(f"cwp{j}", torch.from_numpy(packed.view(np.int16)).to(getattr(self, f"cw{j}").device))
-            if conv3x3_wide_tileable(w.shape[0], w.shape[1]):          # same power-of-two scale: `unscale` holds for both layouts
-                wide, _ = pack_conv3x3_w96(w)
+            # the 8-channel-stage kernels (same power-of-two scale: `unscale` holds for every layout): 96 output channels per
+            # workgroup where the shape allows, else 48 with three workgroups per CU
+            if conv3x3_wide_tileable(w.shape[0], w.shape[1]):
+                wide, _ = pack_conv3x3_w96(w, 96)
                 self.register_buffer(f"cwq{j}", torch.from_numpy(wide.view(np.int16)).to(getattr(self, f"cw{j}").device))
+            elif w.shape[0] % 48 == 0 and w.shape[1] % 16 == 0:
+                narrow, _ = pack_conv3x3_w96(w, 48)
+                self.register_buffer(f"cws{j}", torch.from_numpy(narrow.view(np.int16)).to(getattr(self, f"cw{j}").device))
 
     def _conv(self, x: torch.Tensor, j: int, hip, probe):
         """3x3 conv + bias + ReLU.  `hip.conv_impl == "f16x3"`: one fused HIP kernel on the f16 matrix cores (3-term
@@ -284,6 +289,8 @@ class _Block(nn.Module):
             e0.record()
         if use_mfma and hasattr(self, f"cwq{j}") and getattr(hip, "conv_wide", True):
             y = hip.conv3x3_f16x3_w96(x, getattr(self, f"cwq{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
+        elif use_mfma and hasattr(self, f"cws{j}") and getattr(hip, "conv_wide", True):
+            y = hip.conv3x3_f16x3_s8(x, getattr(self, f"cws{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
         elif use_mfma:
             y = hip.conv3x3_f16x3(x, getattr(self, f"cwp{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
         else:

@@ -297,12 +297,17 @@ int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, cons
                            const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W, float w_unscale,
                            int relu, void* stream);
 
-/* ac_conv3x3_f16x3 with 96 output channels per workgroup (C_in % 32 == 0, C_out % 96 == 0; weights packed by
+/* ac_conv3x3_f16x3 with 96 output channels per workgroup (C_in % 16 == 0, C_out % 96 == 0; weights packed by
  * conv_pack.pack_conv3x3_w96: 8-channel stages, tap 8 of four consecutive stages in one k-step).  Same replaced graph nodes
  * (Conv 3x3 + folded BatchNormalization + Relu of Kim_Vocal_1.onnx, reference backends.py:358), same arithmetic; every staged
  * activation byte feeds twice the MFMAs. */
 int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                          int C_out, int H, int W, float w_unscale, int relu, void* stream);
+
+/* The 8-channel-stage kernel with 48 output channels per workgroup, three workgroups per CU (C_in % 16 == 0, C_out % 48 == 0;
+ * conv_pack.pack_conv3x3_w96(w, cob=48)): the layers ac_conv3x3_f16x3_w96 cannot take. */
+int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                        int C_out, int H, int W, float w_unscale, int relu, void* stream);
 
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 

@@ -104,9 +104,24 @@ def test_conv3x3_f16x3_w96_kernel(hip_ctx):
             if not relu:
                 edges = [y[:, :, [0, -1], :] - full[:, :, [0, -1], :], y[:, :, :, [0, -1]] - full[:, :, :, [0, -1]]]
                 assert max(float(e.abs().max()) for e in edges) / float(full.abs().max()) < 2e-6
-    assert not conv3x3_wide_tileable(144, 144) and not conv3x3_wide_tileable(96, 48)
+    assert not conv3x3_wide_tileable(144, 144) and conv3x3_wide_tileable(96, 48) and not conv3x3_wide_tileable(96, 40)
     with pytest.raises(Exception):
-        hip_ctx.conv3x3_f16x3_w96(torch.zeros(1, 48, 8, 32, device=dev), wp, b.to(dev), 96, 1.0)
+        hip_ctx.conv3x3_f16x3_w96(torch.zeros(1, 40, 8, 32, device=dev), wp, b.to(dev), 96, 1.0)
+    # trailing group of two stages (C_in % 32 == 16) and the 48-channel / three-workgroups-per-CU variant on the other levels
+    for ci, co, h, w_, cob in ((48, 96, 16, 64, 96), (16, 96, 8, 32, 96), (48, 48, 256, 3072, 48), (144, 144, 64, 768, 48), (240, 240, 16, 192, 48)):
+        x = (torch.randn(2, ci, h, w_, generator=g) * 2).to(dev)
+        wt = torch.randn(co, ci, 3, 3, generator=g) / np.sqrt(9 * ci)
+        b = torch.randn(co, generator=g) * 0.1
+        packed, unscale = pack_conv3x3_w96(wt.numpy(), cob)
+        wp = torch.from_numpy(packed.view(np.int16)).to(dev)
+        fn = hip_ctx.conv3x3_f16x3_w96 if cob == 96 else hip_ctx.conv3x3_f16x3_s8
+        full = F.conv2d(x.double().cpu(), wt.double(), b.double(), padding=1)
+        y = fn(x, wp, b.to(dev), co, unscale, relu=False).double().cpu()
+        assert float((y - full).abs().max() / full.abs().max()) < 2e-6, (ci, co, cob)
+        edges = [y[:, :, [0, -1], :] - full[:, :, [0, -1], :], y[:, :, :, [0, -1]] - full[:, :, :, [0, -1]]]
+        assert max(float(e.abs().max()) for e in edges) / float(full.abs().max()) < 2e-6
+        y = fn(x, wp, b.to(dev), co, unscale, relu=True).double().cpu()
+        assert float((y - F.relu(full)).abs().max() / full.abs().max()) < 2e-6
 
 
 def test_tdf_linear_f16x3_kernel(hip_ctx):
