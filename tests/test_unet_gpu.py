@@ -269,7 +269,13 @@ def test_first_conv_fused_into_the_3x3_loader_is_bit_identical(hip_ctx):
     a = net.forward_tf(x)
     hip_ctx.fuse_first_conv = False
     try:
-        b = net.forward_tf(x)
-    finally:
+        b = net.forward_tf(x)            # the unfused first 3x3 conv now runs the 8-channel-stage kernel: other summation order
+        hip_ctx.conv_wide = False
+        c = net.forward_tf(x)            # every conv on the 16-channel-stage kernel, the fused loader's order
         hip_ctx.fuse_first_conv = True
-    assert torch.equal(a, b)
+        d = net.forward_tf(x)
+    finally:
+        hip_ctx.fuse_first_conv, hip_ctx.conv_wide = True, True
+    assert torch.equal(c, d)
+    peak = float(a.abs().max())
+    assert float((a - b).abs().max()) / peak < 2e-6 and float((a - c).abs().max()) / peak < 2e-6
