@@ -374,6 +374,31 @@ def test_c2_full_size_track_against_oracle_fixture(hip_ctx, golden_dir, fixture,
     np.testing.assert_allclose(rms, g["vocal_rms_per_second"], rtol=1e-4, atol=1e-4 * peak)
 
 
+def test_threshold_crossing_sensitivity_is_bounded(hip_ctx, golden_dir):
+    """The one live-soak track (of 21) whose result is not index-identical to the oracle's: its manifest cuts, labels and pause
+    cut points are, and the guard boundaries differ in at most one place by at most two samples - the quiet guard's
+    "first sample under the floor" on a slow decay, moved by the 6e-6 stem difference.  This pins that
+    characterisation: a wider deviation is a regression, an exact match is welcome."""
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    g = np.load(golden_dir / "c1_170s_seed64_w17_oracle.npz")
+    mix = signals.c1_sine_silence(170.0, seed=64)
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=17), ctx=hip_ctx, max_items_per_forward=32)
+    backend.load_model()
+    res = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend)).split_track(mix)
+    assert res["cuts_samples"] == g["cuts"].tolist()
+    assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
+    assert np.array_equal(np.asarray([p.cut_point for p in res["pauses"]]), g["pause_cut_points"])
+    got, want = res["sample_boundaries"], g["sample_boundaries"].tolist()
+    assert len(got) == len(want)
+    moved = [(a, b) for a, b in zip(got, want) if a != b]
+    assert len(moved) <= 1 and all(abs(a - b) <= 2 for a, b in moved), moved
+    voc = res["vocal_track"]
+    assert float(np.max(np.abs(voc[: 4 * SR: 7] - g["vocal_head"]))) / float(g["vocal_peak"]) < STEM_RTOL
+
+
 def test_track_pipeline_matches_sequential_processing(hip_ctx):
     """BASELINE config C3 in miniature: six different tracks through `batch.TrackPipeline` (two in flight, own streams,
     shared U-Net weights) give, track by track, exactly what processing them one after the other gives."""
