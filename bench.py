@@ -217,6 +217,8 @@ def main() -> None:
     dev_index = 0 if rehearsal else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # N processes share the host: keep each rank's CPU-side torch / OpenMP pools to its share of the cores
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
         torch.cuda.set_device(dev_index)
         if rehearsal:
             dist.init_process_group(backend="gloo")
