@@ -37,7 +37,7 @@ def load() -> C.CDLL:
                           f"(there is no CPU fallback for the HIP path)")
     lib = C.CDLL(str(path))
     _declare(lib)
-    if lib.ac_abi_version() != 1:
+    if lib.ac_abi_version() != 2:
         raise NativeError("libaudiocut_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -65,25 +65,21 @@ SIGNATURES = {
     "ac_zero_cross_nearest": (C.c_int, [_P, _P, _I64, _P, _I, _I, _P, _P]),
     "ac_quiet_guard_slow": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P]),
     "ac_pause_cut_points": (C.c_int, [_P, _P, _I64, _P, _P, _I, _I, _I, _P, _P, _P]),
-    "ac_mdx_stft": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _P, _P]),
+    "ac_mdx_stft": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _P, _P, _P]),
     "ac_mdx_istft": (C.c_int, [_P, _P, _I, _P, _P, _P]),
     "ac_mdx_assemble_ola": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "ac_mdx_chunk_vocal": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P]),
     "ac_sum_squares": (C.c_int, [_P, _P, _I64, _P, _I, _P]),
-    "ac_bias_relu_inplace": (C.c_int, [_P, _P, _P, _I64, _I, _I64, _P]),
-    "ac_bias_relu_mul_inplace": (C.c_int, [_P, _P, _P, _P, _I64, _I, _I64, _P]),
-    "ac_affine_relu_inplace": (C.c_int, [_P, _P, _P, _P, _I64, _I, _I64, _P]),
-    "ac_affine_relu_add": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I, _I64, _P]),
-    "ac_space_to_depth2x": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "ac_depth_to_space2x_bias_relu_mul": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
-    "ac_conv3x3_f16x3_w96": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
-    "ac_conv3x3_f16x3_s8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
-    "ac_conv3x3_f16x3_first": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
-    "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P]),
+    "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
+    "ac_conv3x3_f16x3_w96": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
+    "ac_conv3x3_f16x3_s8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
+    "ac_conv3x3_f16x3_first": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, C.c_float, C.c_float,
+                                         _P, _P]),
+    "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P, _P, _P]),
+    "ac_tdf_small_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _P, _P]),
     "ac_conv1x1_small": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I64, _I, _P]),
-    "ac_down2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P]),
-    "ac_up2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P]),
+    "ac_down2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P]),
+    "ac_up2x_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P]),
     "ac_pyin_observe": (C.c_int, [_P, _P, _I64, _I, _I, C.c_double, C.c_double, _I, _I, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                   _P, _P, _P, _P]),
     "ac_pyin_viterbi": (C.c_int, [_P, _P, _P, _I64, _I, _I, _P, _P, C.c_double, _P, _P, _P, _P]),
@@ -140,17 +136,6 @@ class Context:
         with torch.cuda.device(self.index):
             _check(self.lib.ac_ctx_create(self.index, C.byref(handle)))
         self._h = handle
-        # 3x3 convs of the U-Net: "f16x3" = ac_conv3x3_f16x3 (f16 MFMA, 3-term hi/lo split), "miopen" = PyTorch/MIOpen float32
-        self.conv_impl = os.environ.get("AUDIOCUT_CONV_IMPL", "f16x3")
-        # the 8-channel-stage conv kernels (ac_conv3x3_f16x3_w96 where C_out % 96 == 0, else ac_conv3x3_f16x3_s8) unless disabled
-        self.conv_wide = os.environ.get("AUDIOCUT_CONV_WIDE", "1") != "0"
-        # TDF layers: "f16x3" = ac_tdf_linear_f16x3 (fused GEMM + affine + ReLU (+ residual)), "rocblas" = float32 rocBLAS + epilogues
-        self.tdf_impl = os.environ.get("AUDIOCUT_TDF_IMPL", "f16x3")
-        # the graph's first 1x1 conv is generated inside the first 3x3 conv's loader (ac_conv3x3_f16x3_first) unless disabled
-        self.fuse_first_conv = os.environ.get("AUDIOCUT_FUSE_FIRST_CONV", "1") != "0"
-        # 2x2 resampling layers: "f16x3" = ac_down2x_f16x3 / ac_up2x_f16x3 (one fused MFMA kernel each),
-        # "gemm" = gather/scatter kernels around a rocBLAS float32 GEMM, "miopen" = strided / transposed convolutions
-        self.resample_impl = os.environ.get("AUDIOCUT_RESAMPLE_IMPL", "f16x3")
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -464,13 +449,15 @@ class Context:
 
     # -- MDX23 ---------------------------------------------------------------------------------------
     def mdx_stft(self, track: torch.Tensor, chunk_start: torch.Tensor, chunk_len: torch.Tensor,
-                 win_index: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 win_index: torch.Tensor, out: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`amax` [n_items] float32, zeroed by the caller: receives max |spectrogram| per item (the first conv's activation scale)."""
         self._chk_f32(track)
         n_items = chunk_start.numel()
         if out is None:
             out = torch.empty((n_items, 4, 256, 3072), dtype=torch.float32, device=self.device)
+        _, pa = self._amax_args(n_items, None, amax)
         _check(self.lib.ac_mdx_stft(self._h, _ptr(track), track.numel(), _ptr(chunk_start), _ptr(chunk_len), _ptr(win_index),
-                                    n_items, _ptr(out), _stream()))
+                                    n_items, _ptr(out), pa, _stream()))
         return out
 
     def mdx_istft(self, spec: torch.Tensor) -> torch.Tensor:
@@ -500,98 +487,49 @@ class Context:
                                            chunk_len.numel(), _ptr(out), _stream()))
         return out
 
-    # -- U-Net epilogues (NCHW float32, in place unless stated) ----------------------------------------
-    @staticmethod
-    def _nchw(x: torch.Tensor):
+    # -- U-Net layers (NCHW float32; `in_amax` / `out_amax`: per-item max |x| of the input / output tensor, include/audiocut_hip.h) --
+    def _amax_args(self, b: int, in_amax: Optional[torch.Tensor], out_amax: Optional[torch.Tensor]):
+        for t in (in_amax, out_amax):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != b or not t.is_contiguous() or t.device != self.device):
+                raise NativeError("amax tensors must be contiguous float32 [batch] on the context's device")
+        return _ptr(in_amax), _ptr(out_amax)
+
+    def _conv3x3(self, fn, name: str, x, w_packed, bias, c_out, w_unscale, relu, out, in_amax, out_amax) -> torch.Tensor:
         if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
-            raise NativeError("epilogue expects a contiguous float32 NCHW tensor")
-        b, c, h, w = x.shape
-        return b * c, c, h * w
-
-    def bias_relu_(self, x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-        rows, c, inner = self._nchw(x)
-        _check(self.lib.ac_bias_relu_inplace(self._h, _ptr(x), _ptr(bias), rows, c, inner, _stream()))
-        return x
-
-    def bias_relu_mul_(self, x: torch.Tensor, bias: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
-        rows, c, inner = self._nchw(x)
-        if skip.shape != x.shape:
-            raise NativeError("skip tensor shape mismatch")
-        self._nchw(skip)
-        _check(self.lib.ac_bias_relu_mul_inplace(self._h, _ptr(x), _ptr(bias), _ptr(skip), rows, c, inner, _stream()))
-        return x
-
-    def affine_relu_(self, x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
-        rows, c, inner = self._nchw(x)
-        _check(self.lib.ac_affine_relu_inplace(self._h, _ptr(x), _ptr(scale), _ptr(shift), rows, c, inner, _stream()))
-        return x
-
-    def affine_relu_add(self, y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual: torch.Tensor,
-                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        rows, c, inner = self._nchw(y)
-        if residual.shape != y.shape:
-            raise NativeError("residual shape mismatch")
-        self._nchw(residual)
-        out = y if out is None else out
-        _check(self.lib.ac_affine_relu_add(self._h, _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), rows, c, inner, _stream()))
-        return out
-
-    def space_to_depth2x(self, x: torch.Tensor) -> torch.Tensor:
-        b, c, h, w = x.shape
-        self._nchw(x)
-        out = torch.empty((b, 4 * c, h // 2, w // 2), dtype=torch.float32, device=self.device)
-        _check(self.lib.ac_space_to_depth2x(self._h, _ptr(x), _ptr(out), b, c, h, w, _stream()))
-        return out
-
-    def depth_to_space2x_bias_relu_mul(self, y4: torch.Tensor, bias: torch.Tensor, skip: Optional[torch.Tensor]) -> torch.Tensor:
-        b, c4, h, w = y4.shape
-        self._nchw(y4)
-        c = c4 // 4
-        out = torch.empty((b, c, 2 * h, 2 * w), dtype=torch.float32, device=self.device)
-        if skip is not None and (tuple(skip.shape) != tuple(out.shape) or not skip.is_contiguous()):
-            raise NativeError("skip tensor shape mismatch")
-        _check(self.lib.ac_depth_to_space2x_bias_relu_mul(self._h, _ptr(y4), _ptr(bias), _ptr(skip), _ptr(out), b, c, h, w, _stream()))
+            raise NativeError(f"{name} expects a contiguous float32 NCHW tensor")
+        b, c_in, h, w = x.shape
+        if out is None:
+            out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
+        pi, po = self._amax_args(b, in_amax, out_amax)
+        _check(fn(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w, float(w_unscale), int(relu), pi, po,
+                  _stream()))
         return out
 
     def conv3x3_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
-                      relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      relu: bool = True, out: Optional[torch.Tensor] = None, in_amax: Optional[torch.Tensor] = None,
+                      out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """3x3 / stride 1 / pad 1 conv on the f16 matrix cores (3-term hi/lo split), fused bias (+ReLU).  NCHW float32."""
-        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
-            raise NativeError("conv3x3_f16x3 expects a contiguous float32 NCHW tensor")
-        b, c_in, h, w = x.shape
-        if out is None:
-            out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
-        _check(self.lib.ac_conv3x3_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
-                                         float(w_unscale), int(relu), _stream()))
-        return out
+        return self._conv3x3(self.lib.ac_conv3x3_f16x3, "conv3x3_f16x3", x, w_packed, bias, c_out, w_unscale, relu, out, in_amax, out_amax)
 
     def conv3x3_f16x3_w96(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
-                          relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """conv3x3_f16x3 with 96 output channels per workgroup (C_in % 32 == 0, C_out % 96 == 0; `pack_conv3x3_w96` weights)."""
-        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
-            raise NativeError("conv3x3_f16x3_w96 expects a contiguous float32 NCHW tensor")
-        b, c_in, h, w = x.shape
-        if out is None:
-            out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
-        _check(self.lib.ac_conv3x3_f16x3_w96(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
-                                             float(w_unscale), int(relu), _stream()))
-        return out
+                          relu: bool = True, out: Optional[torch.Tensor] = None, in_amax: Optional[torch.Tensor] = None,
+                          out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """conv3x3_f16x3 with 96 output channels per workgroup (C_in % 16 == 0, C_out % 96 == 0; `pack_conv3x3_w96` weights)."""
+        return self._conv3x3(self.lib.ac_conv3x3_f16x3_w96, "conv3x3_f16x3_w96", x, w_packed, bias, c_out, w_unscale, relu, out,
+                             in_amax, out_amax)
 
     def conv3x3_f16x3_s8(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
-                         relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         relu: bool = True, out: Optional[torch.Tensor] = None, in_amax: Optional[torch.Tensor] = None,
+                         out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The 8-channel-stage conv kernel with 48 output channels per workgroup (`pack_conv3x3_w96(w, cob=48)` weights)."""
-        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
-            raise NativeError("conv3x3_f16x3_s8 expects a contiguous float32 NCHW tensor")
-        b, c_in, h, w = x.shape
-        if out is None:
-            out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
-        _check(self.lib.ac_conv3x3_f16x3_s8(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w,
-                                            float(w_unscale), int(relu), _stream()))
-        return out
+        return self._conv3x3(self.lib.ac_conv3x3_f16x3_s8, "conv3x3_f16x3_s8", x, w_packed, bias, c_out, w_unscale, relu, out,
+                             in_amax, out_amax)
 
     def conv3x3_f16x3_first(self, spec: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
-                            c_out: int, w_unscale: float, relu: bool = True) -> torch.Tensor:
-        """relu(conv3x3(relu(conv1x1(spec, w1) + b1))) in one kernel: the 1x1 convolution's output never touches HBM."""
+                            c_out: int, w_unscale: float, relu: bool = True, spec_amax: Optional[torch.Tensor] = None,
+                            amax_gain: float = 1.0, amax_offs: float = 0.0, out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """relu(conv3x3(relu(conv1x1(spec, w1) + b1))) in one kernel: the 1x1 convolution's output never touches HBM.
+        `spec_amax * amax_gain + amax_offs` bounds the generated tensor (gain = max row L1 norm of w1, offs = max |b1|)."""
         if spec.dtype != torch.float32 or spec.dim() != 4 or not spec.is_contiguous():
             raise NativeError("conv3x3_f16x3_first expects a contiguous float32 NCHW tensor")
         b, c0, h, w = spec.shape
@@ -599,12 +537,15 @@ class Context:
         if w1.shape[1] != c0 or not w1.is_contiguous():
             raise NativeError("conv3x3_f16x3_first: w1 must be [C_in, C0(,1,1)] contiguous")
         out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
+        pi, po = self._amax_args(b, spec_amax, out_amax)
         _check(self.lib.ac_conv3x3_f16x3_first(self._h, _ptr(spec), _ptr(w1), _ptr(b1), _ptr(w_packed), _ptr(bias), _ptr(out), b, c0,
-                                               w1.shape[0], c_out, h, w, float(w_unscale), int(relu), _stream()))
+                                               w1.shape[0], c_out, h, w, float(w_unscale), int(relu), pi, float(amax_gain),
+                                               float(amax_offs), po, _stream()))
         return out
 
     def tdf_linear_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, n_out: int, scale: torch.Tensor, shift: torch.Tensor,
-                         w_unscale: float, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         w_unscale: float, resid: Optional[torch.Tensor] = None, in_amax: Optional[torch.Tensor] = None,
+                         out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """TDF layer on the f16 matrix cores: relu(scale[c] * (x @ W^T) + shift[c]) (+ resid) over the last axis of an
         NCHW float32 tensor [B, C, T, K] -> [B, C, T, n_out].  Shapes the kernel cannot tile raise NativeError."""
         if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
@@ -613,8 +554,23 @@ class Context:
         out = torch.empty((b, c, t, n_out), dtype=torch.float32, device=self.device)
         if resid is not None and (resid.shape != out.shape or not resid.is_contiguous() or resid.dtype != torch.float32):
             raise NativeError("tdf_linear_f16x3: residual must match the output")
+        pi, po = self._amax_args(b, in_amax, out_amax)
         _check(self.lib.ac_tdf_linear_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(resid), _ptr(out),
-                                            b * c * t, n_out, k, t, c, float(w_unscale), _stream()))
+                                            b * c * t, n_out, k, t, c, float(w_unscale), pi, po, _stream()))
+        return out
+
+    def tdf_small_fused(self, x: torch.Tensor, w1_packed: torch.Tensor, w2_packed: torch.Tensor, hidden: int, scale1: torch.Tensor,
+                        shift1: torch.Tensor, scale2: torch.Tensor, shift2: torch.Tensor,
+                        out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x + relu(bn(linear(relu(bn(linear(x)))))) over the last axis, both narrow TDF layers in one exact-float32 kernel
+        (`conv_pack.pack_tdf_small` weights; F % 16 == 0, hidden <= 48)."""
+        if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+            raise NativeError("tdf_small_fused expects a contiguous float32 NCHW tensor")
+        b, c, t, f = x.shape
+        out = torch.empty_like(x)
+        _, po = self._amax_args(b, None, out_amax)
+        _check(self.lib.ac_tdf_small_fused(self._h, _ptr(x), _ptr(w1_packed), _ptr(w2_packed), _ptr(scale1), _ptr(shift1), _ptr(scale2),
+                                           _ptr(shift2), _ptr(out), b * c * t, f, int(hidden), t, c, po, _stream()))
         return out
 
     def conv1x1_small(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
@@ -629,17 +585,21 @@ class Context:
         _check(self.lib.ac_conv1x1_small(self._h, _ptr(x), _ptr(w2), _ptr(bias), _ptr(out), b, c, w2.shape[0], h * w, int(relu), _stream()))
         return out
 
-    def down2x_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float) -> torch.Tensor:
+    def down2x_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float,
+                     in_amax: Optional[torch.Tensor] = None, out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """2x2 / stride-2 conv + bias + ReLU, one fused MFMA kernel (space-to-depth gather in the loader).  NCHW float32."""
         if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
             raise NativeError("down2x_f16x3 expects a contiguous float32 NCHW tensor")
         b, c, h, w = x.shape
         out = torch.empty((b, c_out, h // 2, w // 2), dtype=torch.float32, device=self.device)
-        _check(self.lib.ac_down2x_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c, c_out, h, w, float(w_unscale), _stream()))
+        pi, po = self._amax_args(b, in_amax, out_amax)
+        _check(self.lib.ac_down2x_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c, c_out, h, w, float(w_unscale),
+                                        pi, po, _stream()))
         return out
 
     def up2x_f16x3(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float,
-                   skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   skip: Optional[torch.Tensor] = None, in_amax: Optional[torch.Tensor] = None,
+                   out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """2x2 / stride-2 transposed conv + bias + ReLU (* skip), one fused MFMA kernel (depth-to-space in the epilogue)."""
         if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
             raise NativeError("up2x_f16x3 expects a contiguous float32 NCHW tensor")
@@ -647,8 +607,9 @@ class Context:
         out = torch.empty((b, c_out, 2 * h, 2 * w), dtype=torch.float32, device=self.device)
         if skip is not None and (skip.shape != out.shape or not skip.is_contiguous() or skip.dtype != torch.float32):
             raise NativeError("up2x_f16x3: skip must match the output")
+        pi, po = self._amax_args(b, in_amax, out_amax)
         _check(self.lib.ac_up2x_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(skip), _ptr(out), b, c, c_out, h, w,
-                                      float(w_unscale), _stream()))
+                                      float(w_unscale), pi, po, _stream()))
         return out
 
     def mean_square(self, x: torch.Tensor) -> float:

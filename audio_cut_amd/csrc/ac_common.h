@@ -65,6 +65,39 @@ __device__ inline float wave_max_f32(float v) {
     return v;
 }
 
+// ---- per-item activation scale of the split-f16 MFMA kernels -------------------------------------------------
+// x = xh + xl with xh = f16(x * s), xl = f16(x * s - xh): without s the low part is a float16 subnormal for |x| < 6e-2 and
+// the pair carries an ABSOLUTE error floor of 2^-25 however small the tensor is (decays into silence lose their relative
+// precision).  Every kernel that writes a tensor a split-f16 kernel reads therefore also reduces max|x| per batch item into
+// `amax[item]` (one ordered-bits atomicMax per wave); the reader scales by the power of two that puts that maximum in
+// [2^14, 2^15) and folds the inverse into its epilogue.  Power-of-two scaling is exact, so values whose low part is a normal
+// float16 either way round identically; the floor becomes max|x| * 2^-40, and nothing saturates below 2^127.
+__device__ inline float ac_act_scale(const float* __restrict__ amax, int item, float gain, float offs, float* inv) {
+    float s = 1.f;
+    *inv = 1.f;
+    if (amax) {
+        const float a = amax[item] * gain + offs;
+        if (a > 0.f && a < 3.0e38f) {
+            int e;
+            (void)frexpf(a, &e);                    // a = m * 2^e, m in [0.5, 1)
+            e = 15 - e;
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            s = ldexpf(1.f, e);
+            *inv = ldexpf(1.f, -e);
+        }
+    }
+    // `item` is uniform over the wave at every call site: keep the two factors in scalar registers
+    *inv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(*inv)));
+    s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
+    return s;
+}
+// m = max |v| over this thread's outputs (>= 0; NaNs never enter through fmaxf): wave reduce, one atomic per wave.
+__device__ inline void ac_amax_commit(float m, float* __restrict__ slot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, AC_WAVE));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+}
+
 // Block-wide sum of doubles for blockDim.x == 256 (4 waves); result valid in every thread.
 __device__ inline double block_sum_f64_256(double v, double* smem4) {
     v = wave_sum_f64(v);

@@ -59,7 +59,9 @@ template <bool RELU, bool FIRST>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int C_in, int C_out, int H, int W, float w_unscale, int bw,
-                                                          const float* __restrict__ w1, const float* __restrict__ b1, int C0) {
+                                                          const float* __restrict__ w1, const float* __restrict__ b1, int C0,
+                                                          const float* __restrict__ in_amax, float* __restrict__ out_amax,
+                                                          float amax_gain, float amax_offs) {
     // one LDS arena: [hi patch | lo patch | weight fragments] during the K loop, re-used as the output staging tile
     // The plain kernel (DMA) double-buffers the weight fragments - even stages (4 k-steps) in one buffer, odd stages (5) in
     // the other - and fills them with global_load_lds (no registers, issued a stage ahead): 25,600 + 24,576 + 30,720 =
@@ -92,6 +94,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     const int n_cb = C_in / CV_CB;
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * (FIRST ? C0 : C_in) * plane;
+    // per-item power-of-two activation scale (ac_common.h).  FIRST: in_amax is max|spectrogram|; the tensor that is split is the
+    // generated relu(w1 x + b1), bounded by amax * max_c sum_j |w1[c][j]| + max_c |b1[c]| (amax_gain, amax_offs from the host)
+    float act_inv;
+    const float act_s = ac_act_scale(in_amax, b, amax_gain, amax_offs, &act_inv);
+    const float unscale = w_unscale * act_inv;
 
     f32x4 acc[CV_MT][4];
 #pragma unroll
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fminf(fmaxf(FIRST ? gen[q][k] : v4[q][k], -65504.f), 65504.f);
+                    const float v = fminf(fmaxf((FIRST ? gen[q][k] : v4[q][k]) * act_s, -65504.f), 65504.f);
                     const _Float16 hv = (_Float16)v;                   // v_cvt_f16_f32, round to nearest even
                     h4[q] = f16_bits(hv);
                     l4[q] = f16_bits((_Float16)(v - (float)hv));
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     }
     // ---- epilogue: accumulators (D[row = (lane>>4)*4 + r][col = lane&15]) -> LDS tile [co][row][x] -> 128-byte row stores
     __syncthreads();                     // all waves done with the stage buffers
+    float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < CV_MT; ++m) {
 #pragma unroll
@@ -300,8 +308,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = m * 16 + g * 4 + r;
-                float v = acc[m][q][r] * w_unscale + bias[cob * CV_COB + co];
+                float v = acc[m][q][r] * unscale + bias[cob * CV_COB + co];
                 if (RELU) v = fmaxf(v, 0.f);
+                vmax = fmaxf(vmax, fabsf(v));
                 s_out[(co * CV_TH + ty) * CV_OUT_STRIDE + tx] = v;
             }
         }
@@ -315,10 +324,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         const float4 v = *reinterpret_cast<const float4*>(&s_out[line * CV_OUT_STRIDE + 4 * q4]);
         *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
     }
+    if (out_amax) ac_amax_commit(vmax, out_amax + b);
 }
 
 static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
-                     int H, int W, float w_unscale, int relu, void* stream, const float* w1, const float* b1, int C0) {
+                     int H, int W, float w_unscale, int relu, void* stream, const float* w1, const float* b1, int C0,
+                     const float* in_amax, float* out_amax, float amax_gain, float amax_offs) {
     AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
     AC_REQUIRE(B > 0 && C_in > 0 && C_in % CV_CB == 0 && C_out > 0 && C_out % CV_COB == 0, "C_in % 16 == 0 and C_out % 48 == 0");
     AC_REQUIRE(H > 0 && H % CV_TH == 0 && W > 0 && W % CV_TW == 0, "H % 8 == 0 and W % 32 == 0");
@@ -332,24 +343,29 @@ static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const fl
     const f16x8* wp = (const f16x8*)w_packed;
     if (w1) {
         AC_REQUIRE(b1 && C0 >= 1 && C0 <= 4 && C_in <= 64, "fused first conv: 1 <= C0 <= 4, C_in <= 64");
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0);
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0, in_amax, out_amax, amax_gain, amax_offs);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0, in_amax, out_amax, amax_gain, amax_offs);
     } else {
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0);
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0, in_amax, out_amax, 1.f, 0.f);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0, in_amax, out_amax, 1.f, 0.f);
     }
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
 
 extern "C" int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                                 int C_out, int H, int W, float w_unscale, int relu, void* stream) {
-    return cv_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, nullptr, nullptr, 0);
+                                 int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax,
+                                 void* stream) {
+    return cv_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, nullptr, nullptr, 0, in_amax, out_amax,
+                     1.f, 0.f);
 }
 
 extern "C" int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,
                                        const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W,
-                                       float w_unscale, int relu, void* stream) {
+                                       float w_unscale, int relu, const float* spec_amax, float amax_gain, float amax_offs,
+                                       float* out_amax, void* stream) {
     AC_REQUIRE(w1 && b1, "null pointer");
-    return cv_launch(ctx, spec, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, w1, b1, C0);
+    AC_REQUIRE(amax_gain >= 0.f && amax_offs >= 0.f, "amax bound terms must be non-negative");
+    return cv_launch(ctx, spec, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, w1, b1, C0, spec_amax, out_amax,
+                     amax_gain, amax_offs);
 }

@@ -35,7 +35,8 @@ __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast
 template <int MT, int OCC, bool RELU>
 __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                              int C_in, int C_out, int H, int W, float w_unscale, int bw) {
+                                                              int C_in, int C_out, int H, int W, float w_unscale, int bw,
+                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax) {
     constexpr int W9_MT = MT, W9_COB = 16 * MT;
     constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
     constexpr int EP_M = (MT == 6) ? 3 : 2;                   // row tiles per epilogue pass (the output tile must fit the arena)
@@ -62,6 +63,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     const int n_cb = C_in / W9_CB;                                             // even: the stage that issues a shared step is always odd
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * C_in * plane;
+    float act_inv;
+    const float act_s = ac_act_scale(in_amax, b, 1.f, 0.f, &act_inv);          // per-item power-of-two activation scale (ac_common.h)
+    const float unscale = w_unscale * act_inv;
 
     f32x4 acc[W9_MT][4];
 #pragma unroll
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fminf(fmaxf(v4[q][k], -65504.f), 65504.f);
+                    const float v = fminf(fmaxf(v4[q][k] * act_s, -65504.f), 65504.f);
                     const _Float16 hv = (_Float16)v;
                     h4[q] = w9_bits(hv);
                     l4[q] = w9_bits((_Float16)(v - (float)hv));
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
         }
     }
     // ---- epilogue in passes of EP_M row tiles through the LDS tile [co][row][x] -> 128-byte row stores
+    float vmax = 0.f;
 #pragma unroll
     for (int m0 = 0; m0 < W9_MT; m0 += EP_M) {
         const int n_m = (W9_MT - m0) < EP_M ? (W9_MT - m0) : EP_M;
@@ -192,8 +197,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int co = mm * 16 + g * 4 + r;
-                        float v = acc[m][q][r] * w_unscale + bias[cob * W9_COB + m0 * 16 + co];
+                        float v = acc[m][q][r] * unscale + bias[cob * W9_COB + m0 * 16 + co];
                         if (RELU) v = fmaxf(v, 0.f);
+                        vmax = fmaxf(vmax, fabsf(v));
                         s_out[(co * W9_TH + ty) * W9_OUT_STRIDE + tx] = v;
                     }
                 }
@@ -208,10 +214,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
             *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
         }
     }
+    if (out_amax) ac_amax_commit(vmax, out_amax + b);
 }
 
 static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
-                     int H, int W, float w_unscale, int relu, void* stream, int cob_width) {
+                     int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream, int cob_width) {
     AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
     AC_REQUIRE(B > 0 && C_in > 0 && C_in % 16 == 0 && C_out > 0 && C_out % cob_width == 0, "C_in % 16 == 0 and C_out % (96 or 48) == 0");
     AC_REQUIRE(H > 0 && H % W9_TH == 0 && W > 0 && W % W9_TW == 0, "H % 8 == 0 and W % 32 == 0");
@@ -224,22 +231,24 @@ static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const fl
     hipStream_t st = (hipStream_t)stream;
     const f16x8* wp = (const f16x8*)w_packed;
     if (cob_width == 96) {
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
     } else {
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw);
+        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
+        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
     }
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
 
 extern "C" int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                                     int C_out, int H, int W, float w_unscale, int relu, void* stream) {
-    return w9_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, 96);
+                                     int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax,
+                                     void* stream) {
+    return w9_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, in_amax, out_amax, stream, 96);
 }
 
 extern "C" int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                                    int C_out, int H, int W, float w_unscale, int relu, void* stream) {
-    return w9_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, 48);
+                                    int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax,
+                                    void* stream) {
+    return w9_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, in_amax, out_amax, stream, 48);
 }

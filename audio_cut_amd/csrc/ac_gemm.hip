@@ -29,7 +29,8 @@ template <int NT, bool RESID>
 __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ resid, float* __restrict__ y,
-                                                             int n_mblk, int N, int K, int T, int C, float w_unscale) {
+                                                             int n_mblk, int N, int K, int T, int C, float w_unscale,
+                                                             const float* __restrict__ in_amax, float* __restrict__ out_amax) {
     constexpr int BN = 32 * NT;                       // columns per workgroup
     constexpr int BFRAGS = 2 * (BN / 16) * 64;        // 16-byte weight fragments per stage (hi, lo)
     constexpr int B_ITERS = BFRAGS / 256;             // 6 (NT = 6) or 3
@@ -57,6 +58,11 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     const size_t m0 = (size_t)mb * GM_BM;
     const int n0 = nb * BN;
     const int n_stage = K / GM_BK;
+    // per-item power-of-two activation scale (ac_common.h); a 128-row tile lies inside one item ((C * T) % 128 == 0, checked on the host)
+    const int item = (int)(m0 / ((size_t)C * T));
+    float act_inv;
+    const float act_s = ac_act_scale(in_amax, item, 1.f, 0.f, &act_inv);
+    const float unscale = w_unscale * act_inv;
 
     f32x4 acc[GM_MT][NT];
 #pragma unroll
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
             unsigned short h[4], l[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float c = fminf(fmaxf(v[q], -65504.f), 65504.f);
+                const float c = fminf(fmaxf(v[q] * act_s, -65504.f), 65504.f);
                 const _Float16 hv = (_Float16)c;
                 h[q] = gm_f16_bits(hv);
                 l[q] = gm_f16_bits((_Float16)(c - (float)hv));
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
         for (int i = 0; i < E_ITERS; ++i) { int c; rr[0][i] = *reinterpret_cast<const float4*>(resid + out_offset(0, i, c)); }
     }
     __syncthreads();                     // every wave is done reading the stage buffers
+    float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < GM_MT; ++m) {
 #pragma unroll
@@ -166,25 +173,28 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
             const int row = e / ROW_F4, q4 = e - row * ROW_F4;
             int c;
             const size_t o = out_offset(m, i, c);
-            const float sc = scale[c] * w_unscale, sh = shift[c];
+            const float sc = scale[c] * unscale, sh = shift[c];
             float4 v = *reinterpret_cast<const float4*>(&so[row * OSTRIDE + 4 * q4]);
             v.x = fmaxf(v.x * sc + sh, 0.f); v.y = fmaxf(v.y * sc + sh, 0.f);
             v.z = fmaxf(v.z * sc + sh, 0.f); v.w = fmaxf(v.w * sc + sh, 0.f);
             if (RESID) { const float4 q = rr[m & 1][i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             *reinterpret_cast<float4*>(y + o) = v;
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (out_amax) ac_amax_commit(vmax, out_amax + item);
 }
 
 extern "C" int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
                                     const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale,
-                                    void* stream) {
+                                    const float* in_amax, float* out_amax, void* stream) {
     AC_REQUIRE(ctx && x && w_packed && scale && shift && y, "null pointer");
     AC_REQUIRE(M > 0 && M % GM_BM == 0, "M % 128 == 0");
     AC_REQUIRE(K > 0 && K % GM_BK == 0, "K % 32 == 0");
     AC_REQUIRE(N > 0 && N % 96 == 0, "N % 96 == 0");
     AC_REQUIRE(T > 0 && C > 0, "T, C > 0");
+    AC_REQUIRE((!in_amax && !out_amax) || ((long long)C * T) % GM_BM == 0, "per-item amax needs (C * T) % 128 == 0");
     const bool wide = (N % 192) == 0;
     const long long n_mblk = M / GM_BM;
     long long nblk = n_mblk * (N / (wide ? 192 : 96));
@@ -193,11 +203,11 @@ extern "C" int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_pa
     hipStream_t st = (hipStream_t)stream;
     const f16x8* wp = (const f16x8*)w_packed;
     if (wide) {
-        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<6, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
-        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<6, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
+        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<6, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
+        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<6, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
     } else {
-        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<3, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
-        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<3, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale);
+        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<3, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
+        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<3, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
     }
     AC_LAUNCH_CHECK();
     return AC_OK;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_mdx_stft(const float* __restrict__ trac
                                                   const int64_t* __restrict__ chunk_len,
                                                   const int32_t* __restrict__ win_index,
                                                   const float2* __restrict__ tw, const float* __restrict__ hann,
-                                                  float* __restrict__ spec) {
+                                                  float* __restrict__ spec, float* __restrict__ spec_amax) {
     __shared__ float2 s_a[MDX_M];
     __shared__ float2 s_b[MDX_M];
     const int t = blockIdx.x;            // frame
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void k_mdx_stft(const float* __restrict__ trac
     const float2* Z = fft3072_f32(s_a, s_b, tw);
     float* out = spec + (size_t)item * 4 * MDX_T * MDX_F + (size_t)t * MDX_F;
     const size_t cstride = (size_t)MDX_T * MDX_F;
+    float vmax = 0.f;
     for (int k = threadIdx.x; k < MDX_F; k += 256) {
         const float2 zk = Z[k];
         const float2 zn = Z[(MDX_M - k) % MDX_M];
@@ -115,15 +116,17 @@ __global__ __launch_bounds__(256) void k_mdx_stft(const float* __restrict__ trac
         out[cstride + k] = im;             // L.im
         out[2 * cstride + k] = re;         // R.re  (mono input duplicated to both channels, backends.py:269-270)
         out[3 * cstride + k] = im;         // R.im
+        vmax = fmaxf(vmax, fmaxf(fabsf(re), fabsf(im)));
     }
+    if (spec_amax) ac_amax_commit(vmax, spec_amax + item);     // max |spectrogram| per item: the first conv's activation scale
 }
 
 extern "C" int ac_mdx_stft(ac_ctx* ctx, const float* track, int64_t n, const int64_t* chunk_start, const int64_t* chunk_len,
-                           const int32_t* win_index, int n_items, float* spec_out, void* stream) {
+                           const int32_t* win_index, int n_items, float* spec_out, float* spec_amax, void* stream) {
     AC_REQUIRE(ctx && track && chunk_start && chunk_len && win_index && spec_out, "null pointer");
     AC_REQUIRE(n > 0 && n_items > 0 && n_items <= 65535, "n_items must be in [1, 65535]");
     hipLaunchKernelGGL(k_mdx_stft, dim3(MDX_T, n_items), dim3(256), 0, (hipStream_t)stream, track, n, chunk_start, chunk_len,
-                       win_index, ctx->tw6144, ctx->hann6144, spec_out);
+                       win_index, ctx->tw6144, ctx->hann6144, spec_out, spec_amax);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

@@ -23,17 +23,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define RS_BFRAGS (2 * (RS_BN / 16) * 64)          // 768 16-byte weight fragments per stage
 #define RS_B_ITERS (RS_BFRAGS / 256)               // 3
 
-__device__ inline unsigned rs_pack_hi(float a, float b, unsigned& lo_out) {
-    const float ca = fminf(fmaxf(a, -65504.f), 65504.f), cb = fminf(fmaxf(b, -65504.f), 65504.f);
+__device__ inline unsigned rs_pack_hi(float a, float b, unsigned& lo_out, float s) {
+    const float ca = fminf(fmaxf(a * s, -65504.f), 65504.f), cb = fminf(fmaxf(b * s, -65504.f), 65504.f);
     const _Float16 ha = (_Float16)ca, hb = (_Float16)cb;
     const _Float16 la = (_Float16)(ca - (float)ha), lb = (_Float16)(cb - (float)hb);
     lo_out = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
     return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
 }
 
-__device__ inline void rs_put4(unsigned short* s_hi, unsigned short* s_lo, int off, float a, float b, float c, float d) {
+__device__ inline void rs_put4(unsigned short* s_hi, unsigned short* s_lo, int off, float a, float b, float c, float d, float s) {
     unsigned l0, l1;
-    const unsigned h0 = rs_pack_hi(a, b, l0), h1 = rs_pack_hi(c, d, l1);
+    const unsigned h0 = rs_pack_hi(a, b, l0, s), h1 = rs_pack_hi(c, d, l1, s);
     *reinterpret_cast<uint2*>(&s_hi[off]) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(&s_lo[off]) = make_uint2(l0, l1);
 }
@@ -44,7 +44,8 @@ template <int MODE>
 __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                              const float* __restrict__ bias, const float* __restrict__ skip,
                                                              float* __restrict__ out, int Ci, int Co, int H, int W,
-                                                             int n_stage, int n_nblk, int n_mblk, float w_unscale) {
+                                                             int n_stage, int n_nblk, int n_mblk, float w_unscale,
+                                                             const float* __restrict__ in_amax, float* __restrict__ out_amax) {
     constexpr int A_BYTES = 2 * RS_BM * RS_ASTRIDE * 2;                      // 20480
     constexpr int OSTRIDE_UP = 48 + 4;                                       // up: strip [16 m][48 n]
     constexpr int OSTRIDE_DN = 64 + 4;                                       // down: strip [16 n][64 m]
@@ -70,6 +71,9 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     const int p0 = (mb - b * tiles_per_img) * RS_BM;                         // first pixel of the tile inside its image
     const size_t plane_in = (size_t)H * W;
     const float* xb = x + (size_t)b * Ci * plane_in;
+    float act_inv;
+    const float act_s = ac_act_scale(in_amax, b, 1.f, 0.f, &act_inv);          // per-item power-of-two activation scale (ac_common.h)
+    const float unscale = w_unscale * act_inv;
 
     f32x4 acc[RS_MT][RS_NT];
 #pragma unroll
@@ -127,15 +131,15 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float4 r0 = pre_a[2 * i], r1 = pre_a[2 * i + 1];          // (px0 dx0, px0 dx1, px1 dx0, px1 dx1) for dy = 0 / 1
-                rs_put4(s_hi, s_lo, dn_off[i], r0.x, r0.y, r1.x, r1.y);
-                rs_put4(s_hi, s_lo, dn_off[i] + RS_ASTRIDE, r0.z, r0.w, r1.z, r1.w);
+                rs_put4(s_hi, s_lo, dn_off[i], r0.x, r0.y, r1.x, r1.y, act_s);
+                rs_put4(s_hi, s_lo, dn_off[i] + RS_ASTRIDE, r0.z, r0.w, r1.z, r1.w, act_s);
             }
         } else {
             const int off = (4 * up_q) * RS_ASTRIDE + up_c4 * 4;
-            rs_put4(s_hi, s_lo, off + 0 * RS_ASTRIDE, pre_a[0].x, pre_a[1].x, pre_a[2].x, pre_a[3].x);
-            rs_put4(s_hi, s_lo, off + 1 * RS_ASTRIDE, pre_a[0].y, pre_a[1].y, pre_a[2].y, pre_a[3].y);
-            rs_put4(s_hi, s_lo, off + 2 * RS_ASTRIDE, pre_a[0].z, pre_a[1].z, pre_a[2].z, pre_a[3].z);
-            rs_put4(s_hi, s_lo, off + 3 * RS_ASTRIDE, pre_a[0].w, pre_a[1].w, pre_a[2].w, pre_a[3].w);
+            rs_put4(s_hi, s_lo, off + 0 * RS_ASTRIDE, pre_a[0].x, pre_a[1].x, pre_a[2].x, pre_a[3].x, act_s);
+            rs_put4(s_hi, s_lo, off + 1 * RS_ASTRIDE, pre_a[0].y, pre_a[1].y, pre_a[2].y, pre_a[3].y, act_s);
+            rs_put4(s_hi, s_lo, off + 2 * RS_ASTRIDE, pre_a[0].z, pre_a[1].z, pre_a[2].z, pre_a[3].z, act_s);
+            rs_put4(s_hi, s_lo, off + 3 * RS_ASTRIDE, pre_a[0].w, pre_a[1].w, pre_a[2].w, pre_a[3].w, act_s);
         }
     };
 
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     // ---- epilogues: D[row m = (lane >> 4) * 4 + r][col n = lane & 15]; strips are wave-private (LDS is in-order per wave)
     const int g = lane >> 4, px = lane & 15;
     __syncthreads();                     // every wave is done reading the stage buffers
+    float vmax = 0.f;
     if (MODE == 0) {
         // down: NCHW output, pixels contiguous per channel.  Per n-tile: strip [16 n][64 m] -> 256-byte runs per channel.
         float* so = s_out + wave * 16 * OSTRIDE_DN;
@@ -190,8 +195,9 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 if (co < Co) {
                     const float bv = bias[co];
                     float4 v = *reinterpret_cast<const float4*>(&so[nn * OSTRIDE_DN + 4 * q4]);
-                    v.x = fmaxf(v.x * w_unscale + bv, 0.f); v.y = fmaxf(v.y * w_unscale + bv, 0.f);
-                    v.z = fmaxf(v.z * w_unscale + bv, 0.f); v.w = fmaxf(v.w * w_unscale + bv, 0.f);
+                    v.x = fmaxf(v.x * unscale + bv, 0.f); v.y = fmaxf(v.y * unscale + bv, 0.f);
+                    v.z = fmaxf(v.z * unscale + bv, 0.f); v.w = fmaxf(v.w * unscale + bv, 0.f);
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
                     *reinterpret_cast<float4*>(out + ((size_t)b * Co + co) * plane_out + p0 + wm * 64 + 4 * q4) = v;
                 }
             }
@@ -238,18 +244,20 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 const float bv = bias[co];
                 const float2 a0 = *reinterpret_cast<const float2*>(&so[(2 * mp) * OSTRIDE_UP + nn]);       // pixel 2mp:   dx 0, 1
                 const float2 a1 = *reinterpret_cast<const float2*>(&so[(2 * mp + 1) * OSTRIDE_UP + nn]);   // pixel 2mp+1: dx 0, 1
-                float4 v = make_float4(fmaxf(a0.x * w_unscale + bv, 0.f), fmaxf(a0.y * w_unscale + bv, 0.f),
-                                       fmaxf(a1.x * w_unscale + bv, 0.f), fmaxf(a1.y * w_unscale + bv, 0.f));
+                float4 v = make_float4(fmaxf(a0.x * unscale + bv, 0.f), fmaxf(a0.y * unscale + bv, 0.f),
+                                       fmaxf(a1.x * unscale + bv, 0.f), fmaxf(a1.y * unscale + bv, 0.f));
                 if (skip) { const float4 q = sk[m & 1][i]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 *reinterpret_cast<float4*>(out + o) = v;
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (out_amax) ac_amax_commit(vmax, out_amax + b);
 }
 
 static int rs_launch(int mode, ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out,
-                     int B, int Ci, int Co, int H, int W, float w_unscale, void* stream) {
+                     int B, int Ci, int Co, int H, int W, float w_unscale, const float* in_amax, float* out_amax, void* stream) {
     AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
     AC_REQUIRE(B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0, "positive sizes");
     long long P;
@@ -270,20 +278,21 @@ static int rs_launch(int mode, ac_ctx* ctx, const float* x, const void* w_packed
     dim3 grid((unsigned)nblk), block(256);
     if (mode == 0)
         hipLaunchKernelGGL(k_resample2x_f16x3<0>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, skip, out,
-                           Ci, Co, H, W, n_stage, n_nblk, (int)n_mblk, w_unscale);
+                           Ci, Co, H, W, n_stage, n_nblk, (int)n_mblk, w_unscale, in_amax, out_amax);
     else
         hipLaunchKernelGGL(k_resample2x_f16x3<1>, grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, skip, out,
-                           Ci, Co, H, W, n_stage, n_nblk, (int)n_mblk, w_unscale);
+                           Ci, Co, H, W, n_stage, n_nblk, (int)n_mblk, w_unscale, in_amax, out_amax);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
 
 extern "C" int ac_down2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                                int C_out, int H, int W, float w_unscale, void* stream) {
-    return rs_launch(0, ctx, x, w_packed, bias, nullptr, out, B, C_in, C_out, H, W, w_unscale, stream);
+                                int C_out, int H, int W, float w_unscale, const float* in_amax, float* out_amax, void* stream) {
+    return rs_launch(0, ctx, x, w_packed, bias, nullptr, out, B, C_in, C_out, H, W, w_unscale, in_amax, out_amax, stream);
 }
 
 extern "C" int ac_up2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out,
-                              int B, int C_in, int C_out, int H, int W, float w_unscale, void* stream) {
-    return rs_launch(1, ctx, x, w_packed, bias, skip, out, B, C_in, C_out, H, W, w_unscale, stream);
+                              int B, int C_in, int C_out, int H, int W, float w_unscale, const float* in_amax, float* out_amax,
+                              void* stream) {
+    return rs_launch(1, ctx, x, w_packed, bias, skip, out, B, C_in, C_out, H, W, w_unscale, in_amax, out_amax, stream);
 }

@@ -9,7 +9,7 @@ describe_input / fallback_to_cpu` discovered with `getattr`, `:134-135,183-208,2
   ---------------------------------------------------   -------------------------------------------------
   numpy pad/window copies (`:268-281,306-330`)           index math inside ac_mdx_stft (no copies)
   torch.stft -> .cpu().numpy() (`:355-356`)              ac_mdx_stft, stays in HBM
-  ORT session.run (`:358`)                               TfcTdfNet (PyTorch-ROCm conv stacks, MFMA)
+  ORT session.run (`:358`)                               TfcTdfNet (one MFMA kernel per layer)
   torch.from_numpy().to(device); torch.istft (`:375-376`) ac_mdx_istft, stays in HBM
   numpy crop / mix - stem / mean (`:389-406`)            ac_mdx_assemble_ola (fused with the OLA of
   + host OLA in enhanced_vocal_separator.py:423-458       enhanced_vocal_separator.py)
@@ -219,9 +219,10 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             b = min(n_items, a + step)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timings is not None else None
             if ev: ev[0].record()
-            spec = hip.mdx_stft(track_dev, d_cs[a:b].contiguous(), d_cl[a:b].contiguous(), d_wi[a:b].contiguous())
+            amax = torch.zeros(b - a, dtype=torch.float32, device=hip.device)     # max |spec| per item: the first conv's activation scale
+            spec = hip.mdx_stft(track_dev, d_cs[a:b].contiguous(), d_cl[a:b].contiguous(), d_wi[a:b].contiguous(), amax=amax)
             if ev: ev[1].record()
-            out = net.forward_tf(spec)
+            out = net.forward_tf(spec, amax)
             del spec
             if ev: ev[2].record()
             wave[a:b] = hip.mdx_istft(out.contiguous())

@@ -137,3 +137,32 @@ def pack_linear(weight: np.ndarray, bn: int = 0) -> Tuple[np.ndarray, float]:
     # -> [N/BN, K/32, 2, BN/16, lane = group * 16 + n_in_tile, 8]
     out = p.transpose(1, 4, 0, 2, 5, 3, 6).reshape(n // bn, k // 32, 2, bn // 16, 64, 8)
     return np.ascontiguousarray(out), 1.0 / scale
+
+
+def tdf_small_tileable(f: int, hidden: int, rows: int) -> bool:
+    """shapes `ac_tdf_small_fused` takes: F % 16 == 0, bottleneck <= 48, rows % 32 == 0."""
+    return f % 16 == 0 and 0 < hidden <= 48 and rows % 32 == 0
+
+
+def pack_tdf_small(w1: np.ndarray, w2: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """The two bias-free Linear weights of a narrow TDF pair (w1 [Hd, F], w2 [F, Hd]) as float32 operand fragments of
+    `v_mfma_f32_16x16x4_f32` for ac_tdf_small_fused (csrc/ac_tdf_small.hip): lane l holds B[k = l >> 4][n = l & 15].
+      w1p [ceil(Hd / 16)][F / 16][64][4]: element i of lane l = w1[16 nt + (l & 15)][16 kk + 4 (l >> 4) + i] - the kernel feeds
+          the four elements of one float4 of x to four k-steps, so k-step i of group kk is column 16 kk + 4 g + i for lane group g
+      w2p [F / 16][ceil(Hd / 4)][64]:     lane l = w2[16 nt + (l & 15)][4 ks + (l >> 4)]
+    Rows / columns beyond Hd are zero.  No scaling: float32 products."""
+    hd, f = w1.shape
+    if w2.shape != (f, hd) or f % 16 or not (0 < hd <= 48):
+        raise ValueError("pack_tdf_small needs w1 [Hd <= 48, F % 16 == 0] and w2 [F, Hd]")
+    lane = np.arange(64)
+    col, grp = lane & 15, lane >> 4
+    nt1, n_kk, n_ks = (hd + 15) // 16, f // 16, (hd + 3) // 4
+    w1z = np.zeros((nt1 * 16, f), np.float32); w1z[:hd] = w1
+    w2z = np.zeros((f, n_ks * 4), np.float32); w2z[:, :hd] = w2
+    rows = (16 * np.arange(nt1)[:, None, None, None] + col[None, None, :, None])                     # [nt][1][64][1]
+    cols = (16 * np.arange(n_kk)[None, :, None, None] + 4 * grp[None, None, :, None] + np.arange(4)[None, None, None, :])
+    w1p = w1z[rows, cols]                                                                              # [nt1][n_kk][64][4]
+    rows2 = 16 * np.arange(f // 16)[:, None, None] + col[None, None, :]
+    cols2 = 4 * np.arange(n_ks)[None, :, None] + grp[None, None, :]
+    w2p = w2z[rows2, cols2]                                                                            # [F/16][n_ks][64]
+    return np.ascontiguousarray(w1p, np.float32), np.ascontiguousarray(w2p, np.float32)

@@ -8,10 +8,10 @@ down-sampling, bottleneck, 5 decoder blocks with 2x2 transposed-conv up-sampling
 frequency-axis bottleneck MLP (f -> f/8 -> f) with BN+ReLU, residual-added).  With growth g=48
 this is 16.7 M parameters = the 66.8 MB ONNX file.
 
-Here batch-norm (inference mode) is folded into the preceding conv / linear so every dense
-contraction is one MIOpen / rocBLAS (MFMA) call followed by a fused bias+ReLU; activations are
-kept in float32 (the reference's precision).  All sub-windows of a track are batched through one
-forward (`MDX23HipBackend.infer_items`) instead of the reference's one-chunk-at-a-time loop.
+Here batch-norm (inference mode) is folded into the preceding conv / linear and every layer is ONE
+hand-written MFMA kernel of libaudiocut_hip.so with bias / affine / ReLU / residual / skip fused into its
+epilogue; activations are kept in float32 (the reference's precision).  All sub-windows of a track are
+batched through one forward (`MDX23HipBackend.separate_track`) instead of the reference's one-chunk-at-a-time loop.
 
 Weights: `Kim_Vocal_1.onnx` cannot be fetched offline, so `synth_weights` builds seeded tensors
 of exactly this architecture, calibrates the batch-norm statistics on a seeded pseudo-spectrogram
@@ -233,7 +233,28 @@ def _fold(weight: np.ndarray, bias: Optional[np.ndarray], w: Weights, bn_name: s
     return wf.astype(np.float32), bf.astype(np.float32)
 
 
+class _AmaxTape:
+    """Per-forward scratch of per-item activation maxima (include/audiocut_hip.h, "amax"): one zeroed float32 [B] row per
+    tensor that a split-float16 kernel will read; the producing kernel reduces max |x| into it, the consumer derives its
+    power-of-two activation scale from it.  One allocation + one memset per forward."""
+
+    ROWS = 96
+
+    def __init__(self, batch: int, device: torch.device):
+        self._buf = torch.zeros((self.ROWS, batch), dtype=torch.float32, device=device)
+        self._next = 0
+
+    def new(self) -> torch.Tensor:
+        if self._next >= self.ROWS:
+            raise RuntimeError("amax tape exhausted")
+        row = self._buf[self._next]
+        self._next += 1
+        return row
+
+
 class _Block(nn.Module):
+    """One TFC-TDF block: l x [3x3 conv + folded BN + ReLU], then x + TDF(x) (two bias-free Linears over F with BN + ReLU)."""
+
     def __init__(self, w: Weights, prefix: str, spec: TfcTdfSpec):
         super().__init__()
         self.l = spec.l
@@ -254,106 +275,124 @@ class _Block(nn.Module):
             self.register_buffer(f"lb{j}", torch.from_numpy(sh.astype(np.float32)).view(1, -1, 1, 1))
 
     def pack_for_hip(self) -> None:
-        """f16 hi/lo fragment-ordered copies of the folded 3x3 weights for ac_conv3x3_f16x3 (and, where the shape allows
-        96 output channels per workgroup, for ac_conv3x3_f16x3_w96)."""
-        from .conv_pack import conv3x3_wide_tileable, pack_conv3x3, pack_conv3x3_w96, pack_linear
+        """Kernel-ready copies of the folded weights: f16 hi/lo MFMA fragments for the 3x3 convs (ac_conv3x3_f16x3 for the fused
+        first conv, ac_conv3x3_f16x3_w96 / _s8 elsewhere) and for the wide TDF layers (ac_tdf_linear_f16x3); float32 fragments
+        for the narrow TDF pairs of the deep levels (ac_tdf_small_fused)."""
+        from .conv_pack import conv3x3_wide_tileable, pack_conv3x3, pack_conv3x3_w96, pack_linear, pack_tdf_small
+        w0 = self.lw0.detach().cpu().numpy(); w1 = self.lw1.detach().cpu().numpy()
+        dev = self.lw0.device
         self._l_unscale = [None, None]
-        for j in range(2):
-            w = getattr(self, f"lw{j}").detach().cpu().numpy()
-            if w.shape[0] % 96 == 0 and w.shape[1] % 32 == 0:
+        if w0.shape[0] % 96 == 0 and w0.shape[1] % 32 == 0 and w1.shape[0] % 96 == 0 and w1.shape[1] % 32 == 0:
+            for j, w in enumerate((w0, w1)):
                 packed, unscale = pack_linear(w)
                 self._l_unscale[j] = unscale
-                self.register_buffer(f"lwp{j}", torch.from_numpy(packed.view(np.int16)).to(getattr(self, f"lw{j}").device))
+                self.register_buffer(f"lwp{j}", torch.from_numpy(packed.view(np.int16)).to(dev))
+        elif w0.shape[1] % 16 == 0 and w0.shape[0] <= 48:
+            p1, p2 = pack_tdf_small(w0, w1)
+            self.register_buffer("lws0", torch.from_numpy(p1).to(dev))
+            self.register_buffer("lws1", torch.from_numpy(p2).to(dev))
         self._w_unscale = []
         for j in range(self.l):
             w = getattr(self, f"cw{j}").detach().cpu().numpy()
+            if w.shape[0] % 48 or w.shape[1] % 16:
+                self._w_unscale.append(None)
+                continue
             packed, unscale = pack_conv3x3(w)
             self._w_unscale.append(unscale)
-            self.register_buffer(f"cwp{j}", torch.from_numpy(packed.view(np.int16)).to(getattr(self, f"cw{j}").device))
+            if j == 0:      # only a block's first conv can be the graph's first 3x3 conv (fused with the 1x1 in front of it)
+                self.register_buffer("cwp0", torch.from_numpy(packed.view(np.int16)).to(dev))
             # the 8-channel-stage kernels (same power-of-two scale: `unscale` holds for every layout): 96 output channels per
             # workgroup where the shape allows, else 48 with three workgroups per CU
             if conv3x3_wide_tileable(w.shape[0], w.shape[1]):
                 wide, _ = pack_conv3x3_w96(w, 96)
-                self.register_buffer(f"cwq{j}", torch.from_numpy(wide.view(np.int16)).to(getattr(self, f"cw{j}").device))
-            elif w.shape[0] % 48 == 0 and w.shape[1] % 16 == 0:
+                self.register_buffer(f"cwq{j}", torch.from_numpy(wide.view(np.int16)).to(dev))
+            else:
                 narrow, _ = pack_conv3x3_w96(w, 48)
-                self.register_buffer(f"cws{j}", torch.from_numpy(narrow.view(np.int16)).to(getattr(self, f"cw{j}").device))
+                self.register_buffer(f"cws{j}", torch.from_numpy(narrow.view(np.int16)).to(dev))
 
-    def _conv(self, x: torch.Tensor, j: int, hip, probe):
-        """3x3 conv + bias + ReLU.  `hip.conv_impl == "f16x3"`: one fused HIP kernel on the f16 matrix cores (3-term
-        hi/lo split, float32-class accuracy); otherwise MIOpen's float32 conv + the fused bias+ReLU epilogue."""
-        use_mfma = getattr(hip, "conv_impl", "f16x3") == "f16x3" and hasattr(self, f"cwp{j}") \
-            and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
+    def _conv(self, x: torch.Tensor, ax: torch.Tensor, j: int, hip, tape: _AmaxTape, probe):
+        """3x3 conv + bias + ReLU: one fused kernel on the f16 matrix cores (3-term hi/lo split, float32-class accuracy)."""
+        from .._native import NativeError
+        if x.shape[2] % 8 or x.shape[3] % 32 or not (hasattr(self, f"cwq{j}") or hasattr(self, f"cws{j}")):
+            raise NativeError(f"3x3 conv of shape {tuple(x.shape)} is not tileable by the HIP kernels (C % 48, C_in % 16, H % 8, W % 32)")
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        if use_mfma and hasattr(self, f"cwq{j}") and getattr(hip, "conv_wide", True):
-            y = hip.conv3x3_f16x3_w96(x, getattr(self, f"cwq{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
-        elif use_mfma and hasattr(self, f"cws{j}") and getattr(hip, "conv_wide", True):
-            y = hip.conv3x3_f16x3_s8(x, getattr(self, f"cws{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
-        elif use_mfma:
-            y = hip.conv3x3_f16x3(x, getattr(self, f"cwp{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True)
+        ay = tape.new()
+        if hasattr(self, f"cwq{j}"):
+            y = hip.conv3x3_f16x3_w96(x, getattr(self, f"cwq{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True,
+                                      in_amax=ax, out_amax=ay)
         else:
-            y = F.conv2d(x, getattr(self, f"cw{j}"), None, padding=self.pad)
+            y = hip.conv3x3_f16x3_s8(x, getattr(self, f"cws{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True,
+                                     in_amax=ax, out_amax=ay)
         if probe is not None:
             e1.record()
             probe.append((e0, e1, 2.0 * x.shape[0] * x.shape[1] * x.shape[1] * 9 * x.shape[2] * x.shape[3]))
-        return y if use_mfma else hip.bias_relu_(y, getattr(self, f"cb{j}"))
+        return y, ay
 
-    def _tdf(self, x: torch.Tensor, hip) -> torch.Tensor:
-        """x + relu(bn(linear(relu(bn(linear(x)))))) over the frequency axis.  `hip.tdf_impl == "f16x3"`: each layer is one
-        fused HIP kernel on the f16 matrix cores (ac_tdf_linear_f16x3: GEMM + per-channel affine + ReLU (+ residual));
-        shapes it cannot tile (the narrow bottleneck widths of the deep levels) and "rocblas" use rocBLAS float32 GEMMs
-        + the fused epilogue kernels."""
+    def _tdf(self, x: torch.Tensor, ax: torch.Tensor, hip, tape: _AmaxTape):
+        """x + relu(bn(linear(relu(bn(linear(x)))))) over the frequency axis: two fused GEMM kernels on the f16 matrix cores
+        (ac_tdf_linear_f16x3: + per-channel affine + ReLU (+ residual)), or one exact-float32 kernel for the narrow pairs of the
+        deep levels (ac_tdf_small_fused)."""
+        from .._native import NativeError
         rows = x.shape[0] * x.shape[1] * x.shape[2]
-        mfma = getattr(hip, "tdf_impl", "f16x3") == "f16x3" and rows % 128 == 0
-        if mfma and hasattr(self, "lwp0"):
-            y = hip.tdf_linear_f16x3(x, self.lwp0, self.lw0.shape[0], self.ls0.view(-1), self.lb0.view(-1), self._l_unscale[0])
-        else:
-            y = hip.affine_relu_(F.linear(x, self.lw0), self.ls0.view(-1), self.lb0.view(-1))
-        if mfma and hasattr(self, "lwp1"):
-            return hip.tdf_linear_f16x3(y, self.lwp1, self.lw1.shape[0], self.ls1.view(-1), self.lb1.view(-1), self._l_unscale[1], resid=x)
-        return hip.affine_relu_add(F.linear(y, self.lw1), self.ls1.view(-1), self.lb1.view(-1), x)
+        ay = tape.new()
+        if hasattr(self, "lwp0") and rows % 128 == 0 and (x.shape[1] * x.shape[2]) % 128 == 0:
+            ah = tape.new()
+            h = hip.tdf_linear_f16x3(x, self.lwp0, self.lw0.shape[0], self.ls0.view(-1), self.lb0.view(-1), self._l_unscale[0],
+                                     in_amax=ax, out_amax=ah)
+            y = hip.tdf_linear_f16x3(h, self.lwp1, self.lw1.shape[0], self.ls1.view(-1), self.lb1.view(-1), self._l_unscale[1], resid=x,
+                                     in_amax=ah, out_amax=ay)
+            return y, ay
+        if hasattr(self, "lws0") and rows % 32 == 0 and (x.shape[1] * x.shape[2]) % 32 == 0:
+            y = hip.tdf_small_fused(x, self.lws0, self.lws1, self.lw0.shape[0], self.ls0.view(-1), self.lb0.view(-1),
+                                    self.ls1.view(-1), self.lb1.view(-1), out_amax=ay)
+            return y, ay
+        raise NativeError(f"TDF of shape {tuple(x.shape)} -> {self.lw0.shape[0]} is not tileable by the HIP kernels")
 
-    def forward(self, x: torch.Tensor, hip=None, probe=None, first=None) -> torch.Tensor:
-        if hip is not None:
-            # `first` = (w1, b1) of the graph's first 1x1 convolution: fused into this block's first 3x3 conv (x is the spectrogram)
-            start = 0
-            if first is not None:
-                if probe is not None:
-                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                spec = x
-                x = hip.conv3x3_f16x3_first(spec, first[0], first[1], self.cwp0, self.cb0, self.cw0.shape[0], self._w_unscale[0], relu=True)
-                if probe is not None:
-                    e1.record()
-                    c = self.cw0.shape[0]
-                    probe.append((e0, e1, 2.0 * spec.shape[0] * c * c * 9 * spec.shape[2] * spec.shape[3]))
-                start = 1
-            for j in range(start, self.l):
-                x = self._conv(x, j, hip, probe)
-            return self._tdf(x, hip)
-        for j in range(self.l):
-            x = F.relu_(F.conv2d(x, getattr(self, f"cw{j}"), getattr(self, f"cb{j}"), padding=self.pad))
-        y = x
-        for j in range(2):
-            y = F.linear(y, getattr(self, f"lw{j}"))
-            y = F.relu_(torch.addcmul(getattr(self, f"lb{j}"), y, getattr(self, f"ls{j}")))
-        return x + y
+    def forward_hip(self, x: torch.Tensor, ax: torch.Tensor, hip, tape: _AmaxTape, probe=None, first=None):
+        """`first` = (w1, b1, gain, offs) of the graph's first 1x1 convolution: fused into this block's first 3x3 conv (x is the
+        spectrogram, ax its per-item max; gain / offs bound the generated tensor)."""
+        start = 0
+        if first is not None:
+            if probe is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            spec = x
+            ay = tape.new()
+            x = hip.conv3x3_f16x3_first(spec, first[0], first[1], self.cwp0, self.cb0, self.cw0.shape[0], self._w_unscale[0], relu=True,
+                                        spec_amax=ax, amax_gain=first[2], amax_offs=first[3], out_amax=ay)
+            ax = ay
+            if probe is not None:
+                e1.record()
+                c = self.cw0.shape[0]
+                probe.append((e0, e1, 2.0 * spec.shape[0] * c * c * 9 * spec.shape[2] * spec.shape[3]))
+            start = 1
+        for j in range(start, self.l):
+            x, ax = self._conv(x, ax, j, hip, tape, probe)
+        return self._tdf(x, ax, hip, tape)
 
 
 class TfcTdfNet(nn.Module):
-    """Inference-only TFC-TDF v2 with folded BN.  Input/output `[B, 4, dim_f, T]` float32."""
+    """Inference-only TFC-TDF v2 with folded BN on the HIP kernels.  Input/output `[B, 4, dim_f, T]` float32.
+
+    Every layer is a kernel of libaudiocut_hip.so; a shape the kernels cannot tile raises `NativeError` - there is no MIOpen /
+    rocBLAS / CPU path (the float32 / float64 PyTorch evaluation of the same folded weights used as the reference in the tests
+    lives in `tests/unet_torch.py`)."""
 
     def __init__(self, weights: Weights, spec: TfcTdfSpec = TfcTdfSpec(), hip=None):
         super().__init__()
         self.spec = spec
-        self.hip = hip          # audio_cut_amd._native.Context: enables the fused HIP epilogues on device tensors
+        self.hip = hip          # audio_cut_amd._native.Context
         self.conv_probe = None  # set to a list to collect (start event, end event, flops) per 3x3 conv launch (bench.py)
+        self.block_tap = None   # callable(name, tensor) invoked with every block's output (tests compare block by block)
         w = weights
         wf, bf = _fold(w["first_conv.weight"], w["first_conv.bias"], w, "first_bn", spec.bn_eps, 0)
         self.register_buffer("first_w", torch.from_numpy(wf))
         self.register_buffer("first_b", torch.from_numpy(bf))
+        # bound of the generated first-layer tensor: |relu(w1 x + b1)| <= max|x| * max_c sum_j |w1[c][j]| + max_c |b1[c]|
+        self._first_gain = float(np.max(np.sum(np.abs(wf.reshape(wf.shape[0], -1).astype(np.float64)), axis=1)))
+        self._first_offs = float(np.max(np.abs(bf.astype(np.float64)))) if bf.size else 0.0
         self.enc = nn.ModuleList(_Block(w, f"enc.{i}", spec) for i in range(spec.n_levels))
         self.dec = nn.ModuleList(_Block(w, f"dec.{i}", spec) for i in range(spec.n_levels))
         self.bottleneck = _Block(w, "bottleneck", spec)
@@ -364,11 +403,6 @@ class TfcTdfNet(nn.Module):
             wf, bf = _fold(w[f"us.{i}.conv.weight"], w[f"us.{i}.conv.bias"], w, f"us.{i}.bn", spec.bn_eps, 1)
             self.register_buffer(f"us_w{i}", torch.from_numpy(wf))
             self.register_buffer(f"us_b{i}", torch.from_numpy(bf))
-            # GEMM forms: down W[co, (tap, ci)], up W[(tap, co), ci] with tap = dy*2 + dx
-            dsw = getattr(self, f"ds_w{i}")                                    # [co, ci, 2, 2]
-            self.register_buffer(f"ds_m{i}", dsw.permute(0, 2, 3, 1).reshape(dsw.shape[0], -1).contiguous())
-            usw = torch.from_numpy(wf)                                         # [ci, co, 2, 2]
-            self.register_buffer(f"us_m{i}", usw.permute(2, 3, 1, 0).reshape(-1, usw.shape[0]).contiguous())
         if hip is not None:
             from .conv_pack import pack_linear
             for blk in [*self.enc, *self.dec, self.bottleneck]:
@@ -386,31 +420,28 @@ class TfcTdfNet(nn.Module):
         self.register_buffer("final_w", torch.from_numpy(np.ascontiguousarray(w["final_conv.weight"])))
         self.register_buffer("final_b", torch.from_numpy(np.ascontiguousarray(w["final_conv.bias"])))
 
-    def _down(self, x: torch.Tensor, i: int, hip) -> torch.Tensor:
-        """2x2 / stride-2 conv + bias + ReLU = space-to-depth gather (HIP) + one [C', 4C] GEMM (rocBLAS) + fused epilogue."""
+    def _down(self, x: torch.Tensor, ax: torch.Tensor, i: int, hip, tape: _AmaxTape):
+        """2x2 / stride-2 conv + bias + ReLU: one fused MFMA kernel (space-to-depth gather in the loader)."""
+        from .._native import NativeError
         b, c, h, w = x.shape
-        impl = getattr(hip, "resample_impl", "f16x3")
-        if impl == "f16x3" and h % 2 == 0 and w % 4 == 0 and ((h // 2) * (w // 2)) % 128 == 0 and c % 8 == 0:
-            return hip.down2x_f16x3(x, getattr(self, f"ds_p{i}"), getattr(self, f"ds_b{i}"), getattr(self, f"ds_w{i}").shape[0],
-                                    self._rs_unscale[f"ds{i}"])
-        if impl == "miopen" or h % 2 or w % 4:
-            return hip.bias_relu_(F.conv2d(x, getattr(self, f"ds_w{i}"), None, stride=2), getattr(self, f"ds_b{i}"))
-        x2 = hip.space_to_depth2x(x).view(b, 4 * c, (h // 2) * (w // 2))
-        y = torch.matmul(getattr(self, f"ds_m{i}"), x2).view(b, -1, h // 2, w // 2)
-        return hip.bias_relu_(y, getattr(self, f"ds_b{i}"))
+        if h % 2 or w % 4 or ((h // 2) * (w // 2)) % 128 or c % 8:
+            raise NativeError(f"down-sampling of shape {tuple(x.shape)} is not tileable by ac_down2x_f16x3")
+        ay = tape.new()
+        y = hip.down2x_f16x3(x, getattr(self, f"ds_p{i}"), getattr(self, f"ds_b{i}"), getattr(self, f"ds_w{i}").shape[0],
+                             self._rs_unscale[f"ds{i}"], in_amax=ax, out_amax=ay)
+        return y, ay
 
-    def _up(self, x: torch.Tensor, i: int, hip, skip: torch.Tensor) -> torch.Tensor:
-        """2x2 / stride-2 transposed conv + bias + ReLU + multiplicative skip = one [4C', C] GEMM + one scatter pass."""
+    def _up(self, x: torch.Tensor, ax: torch.Tensor, i: int, hip, skip: torch.Tensor, tape: _AmaxTape):
+        """2x2 / stride-2 transposed conv + bias + ReLU + multiplicative skip: one fused MFMA kernel (depth-to-space in the epilogue)."""
+        from .._native import NativeError
         b, c, h, w = x.shape
-        impl = getattr(hip, "resample_impl", "f16x3")
         c_out = getattr(self, f"us_w{i}").shape[1]
-        if impl == "f16x3" and w % 4 == 0 and (h * w) % 128 == 0 and (4 * c_out) % 96 == 0:
-            return hip.up2x_f16x3(x, getattr(self, f"us_p{i}"), getattr(self, f"us_b{i}"), c_out, self._rs_unscale[f"us{i}"], skip=skip)
-        if impl == "miopen" or w % 2:
-            y = F.conv_transpose2d(x, getattr(self, f"us_w{i}"), None, stride=2)
-            return hip.bias_relu_mul_(y, getattr(self, f"us_b{i}"), skip)
-        y4 = torch.matmul(getattr(self, f"us_m{i}"), x.view(b, c, h * w)).view(b, -1, h, w)
-        return hip.depth_to_space2x_bias_relu_mul(y4, getattr(self, f"us_b{i}"), skip)
+        if w % 4 or (h * w) % 128 or (4 * c_out) % 96:
+            raise NativeError(f"up-sampling of shape {tuple(x.shape)} is not tileable by ac_up2x_f16x3")
+        ay = tape.new()
+        y = hip.up2x_f16x3(x, getattr(self, f"us_p{i}"), getattr(self, f"us_b{i}"), c_out, self._rs_unscale[f"us{i}"], skip=skip,
+                           in_amax=ax, out_amax=ay)
+        return y, ay
 
     @torch.no_grad()
     def forward(self, spec_in: torch.Tensor) -> torch.Tensor:
@@ -418,42 +449,35 @@ class TfcTdfNet(nn.Module):
         return self.forward_tf(spec_in.transpose(-1, -2).contiguous()).transpose(-1, -2)
 
     @torch.no_grad()
-    def forward_tf(self, spec_tf: torch.Tensor) -> torch.Tensor:
+    def forward_tf(self, spec_tf: torch.Tensor, spec_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """T-major call `[B, 4, T, F]` -> `[B, 4, T, F]`: the graph transposes right after its first 1x1
         conv and right before its last one (1x1 convs commute with the transpose), so the HIP STFT writes
-        and the HIP iSTFT reads this layout directly and no transpose is ever materialised."""
+        and the HIP iSTFT reads this layout directly and no transpose is ever materialised.
+        `spec_amax` [B] = max |spec| per item as ac_mdx_stft reduces it (computed here when absent)."""
+        from .._native import NativeError
+        hip = self.hip
+        if hip is None or not spec_tf.is_cuda:
+            raise NativeError("TfcTdfNet runs on the HIP kernels only: construct it with hip=Context and feed device tensors "
+                              "(tests/unet_torch.py holds the PyTorch reference evaluation)")
         n = self.spec.n_levels
-        hip = self.hip if (self.hip is not None and spec_tf.is_cuda) else None
-        skips: List[torch.Tensor] = []
-        if hip is not None:
-            ends_hip = (spec_tf.shape[2] * spec_tf.shape[3]) % 4 == 0 and spec_tf.is_contiguous()
-            fuse_first = (ends_hip and getattr(hip, "conv_impl", "f16x3") == "f16x3" and getattr(hip, "fuse_first_conv", True)
-                          and hasattr(self.enc[0], "cwp0") and self.first_w.shape[0] <= 64 and spec_tf.shape[1] <= 4 and spec_tf.shape[2] % 8 == 0 and spec_tf.shape[3] % 32 == 0)
-            if fuse_first:
-                x = spec_tf
-            else:
-                x = hip.conv1x1_small(spec_tf, self.first_w, self.first_b, relu=True) if ends_hip \
-                    else hip.bias_relu_(F.conv2d(spec_tf, self.first_w, None), self.first_b)
-            for i in range(n):
-                if i == 0 and fuse_first:
-                    x = self.enc[0](x, hip, self.conv_probe, first=(self.first_w, self.first_b))
-                else:
-                    x = self.enc[i](x, hip, self.conv_probe)
-                skips.append(x)
-                x = self._down(x, i, hip)
-            x = self.bottleneck(x, hip, self.conv_probe)
-            for i in range(n):
-                x = self._up(x, i, hip, skips.pop())
-                x = self.dec[i](x, hip, self.conv_probe)
-            return hip.conv1x1_small(x, self.final_w, self.final_b, relu=False) if ends_hip else F.conv2d(x, self.final_w, self.final_b)
-        x = F.relu_(F.conv2d(spec_tf, self.first_w, self.first_b))
+        b, c0, t, f = spec_tf.shape
+        if not spec_tf.is_contiguous() or c0 > 4 or self.first_w.shape[0] > 64 or t % 8 or f % 32 or not hasattr(self.enc[0], "cwp0"):
+            raise NativeError(f"spectrogram of shape {tuple(spec_tf.shape)} is not tileable by ac_conv3x3_f16x3_first")
+        if spec_amax is None:
+            spec_amax = spec_tf.abs().amax(dim=(1, 2, 3)).contiguous()
+        tape = _AmaxTape(b, spec_tf.device)
+        skips = []
+        x, ax = spec_tf, spec_amax
         for i in range(n):
-            x = self.enc[i](x)
+            first = (self.first_w, self.first_b, self._first_gain, self._first_offs) if i == 0 else None
+            x, ax = self.enc[i].forward_hip(x, ax, hip, tape, self.conv_probe, first=first)
+            if self.block_tap is not None: self.block_tap(f"enc{i}", x)
             skips.append(x)
-            x = F.relu_(F.conv2d(x, getattr(self, f"ds_w{i}"), getattr(self, f"ds_b{i}"), stride=2))
-        x = self.bottleneck(x)
+            x, ax = self._down(x, ax, i, hip, tape)
+        x, ax = self.bottleneck.forward_hip(x, ax, hip, tape, self.conv_probe)
+        if self.block_tap is not None: self.block_tap("bottleneck", x)
         for i in range(n):
-            x = F.relu_(F.conv_transpose2d(x, getattr(self, f"us_w{i}"), getattr(self, f"us_b{i}"), stride=2))
-            x = x.mul_(skips.pop())
-            x = self.dec[i](x)
-        return F.conv2d(x, self.final_w, self.final_b)
+            x, ax = self._up(x, ax, i, hip, skips.pop(), tape)
+            x, ax = self.dec[i].forward_hip(x, ax, hip, tape, self.conv_probe)
+            if self.block_tap is not None: self.block_tap(f"dec{i}", x)
+        return hip.conv1x1_small(x, self.final_w, self.final_b, relu=False)

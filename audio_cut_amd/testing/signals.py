@@ -132,3 +132,22 @@ def voice_with_rests(duration_s: float, seed: int, sr: int = SR) -> np.ndarray:
                 out[b0:b0 + bl] += rng.standard_normal(bl) * 0.004 * np.hanning(bl)
         pos += length + rest
     return out.astype(np.float32)
+
+
+def c5_long_form(duration_s: float = 1800.0, seed: int = 5, sr: int = SR, section_s: float = 60.0, stereo: bool = False) -> np.ndarray:
+    """BASELINE configs[4]: the C2 generator looped with per-section seeds (`seed * 1000 + i`),
+    each section with its own level so no two minutes are alike.  `sr=48000, stereo=True` gives the 48 kHz stereo source the
+    loader leg resamples; `sr=44100` (mono channel mean) is the post-resample parity input."""
+    n = int(round(duration_s * sr))
+    parts = []
+    i = 0
+    got = 0
+    while got < n:
+        length = min(section_s, (n - got) / float(sr))
+        sec = c2_song(length, seed=seed * 1000 + i, sr=sr, stereo=stereo)
+        sec = sec * np.float32(0.55 + 0.45 * ((i * 7) % 10) / 9.0)
+        parts.append(sec)
+        got += sec.shape[-1]
+        i += 1
+    out = np.concatenate(parts, axis=-1)[..., :n]
+    return np.ascontiguousarray(out, dtype=np.float32)

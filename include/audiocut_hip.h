@@ -29,7 +29,7 @@ extern "C" {
 #define AC_E_HIP (-2)       /* a HIP runtime call failed */
 #define AC_E_NOMEM (-3)
 
-#define AC_ABI_VERSION 1
+#define AC_ABI_VERSION 2
 
 typedef struct ac_ctx ac_ctx;
 
@@ -135,6 +135,7 @@ int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const int64_t* a
  * layout; channels L.re, L.im, R.re, R.im of the mono-duplicated input, backends.py:269-270). */
 int ac_mdx_stft(ac_ctx* ctx, const float* track, int64_t n, const int64_t* chunk_start,
                 const int64_t* chunk_len, const int32_t* win_index, int n_items, float* spec_out,
+                float* spec_amax /* [n_items], zeroed by the caller, may be NULL: max |spec| per item (see "amax" below) */,
                 void* stream);
 
 /* external Conv_TDF_net_trim_model.istft (backends.py:376): spec[n_items][4][256][3072] ->
@@ -159,32 +160,7 @@ int ac_mdx_chunk_vocal(ac_ctx* ctx, const float* wave, const int64_t* chunk_len,
 /* enhanced_vocal_separator.py:490-501: float64 partial sums of x^2 (n_partials blocks, summed by the host). */
 int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int n_partials, void* stream);
 
-/* ---- U-Net epilogues ------------------------------------------------------------------------ */
-
-/* The BatchNorm / ReLU / Mul / Add nodes between the Conv / ConvTranspose / MatMul nodes of the graph the
- * reference runs through ORT (separation/backends.py:358), as single streaming passes over NCHW float32
- * activations (row = one (batch, channel) plane of `inner` contiguous elements, channel = row % C,
- * inner % 4 == 0).  The dense contractions themselves stay in MIOpen / rocBLAS.
- *   ac_bias_relu_inplace:      x = relu(x + bias[c])
- *   ac_bias_relu_mul_inplace:  x = relu(x + bias[c]) * skip        (decoder: up-sample then multiplicative skip)
- *   ac_affine_relu_inplace:    x = relu(x * scale[c] + shift[c])   (TDF linear 1)
- *   ac_affine_relu_add:        out = residual + relu(y * scale[c] + shift[c])   (TDF linear 2 + residual) */
-int ac_bias_relu_inplace(ac_ctx* ctx, float* x, const float* bias, int64_t rows, int C, int64_t inner, void* stream);
-int ac_bias_relu_mul_inplace(ac_ctx* ctx, float* x, const float* bias, const float* skip, int64_t rows, int C,
-                             int64_t inner, void* stream);
-int ac_affine_relu_inplace(ac_ctx* ctx, float* x, const float* scale, const float* shift, int64_t rows, int C,
-                           int64_t inner, void* stream);
-int ac_affine_relu_add(ac_ctx* ctx, const float* y, const float* scale, const float* shift, const float* residual,
-                       float* out, int64_t rows, int C, int64_t inner, void* stream);
-
-/* The 2x2 / stride-2 down- and up-sampling convolutions of the same graph as plain GEMMs plus one streaming pass:
- *   ac_space_to_depth2x:               x [B][C][H][W] -> out [B][4][C][H/2][W/2] (tap = dy*2 + dx); a [C', 4C] GEMM
- *                                      and ac_bias_relu_inplace then give relu(conv2x2_s2(x) + b)
- *   ac_depth_to_space2x_bias_relu_mul: y4 [B][4][C][H][W] (a [4C, C_in] GEMM of the input) ->
- *                                      out [B][C][2H][2W] = relu(y4[tap] + bias[c]) * skip (skip may be NULL) */
-int ac_space_to_depth2x(ac_ctx* ctx, const float* x, float* out, int B, int C, int H, int W, void* stream);
-int ac_depth_to_space2x_bias_relu_mul(ac_ctx* ctx, const float* y4, const float* bias, const float* skip, float* out,
-                                      int B, int C, int H, int W, void* stream);
+/* ---- U-Net layers (MFMA kernels; no MIOpen / rocBLAS path) ----------------------------------- */
 
 /* 3x3 convolution (stride 1, pad 1) of the U-Net, NCHW float32 in/out, on the 16-bit matrix cores with a 3-term
  * float16 hi/lo split (x*w ~= xh*wh + xh*wl + xl*wh; products exact in the float32 MFMA accumulator): float32-class
@@ -192,9 +168,17 @@ int ac_depth_to_space2x_bias_relu_mul(ac_ctx* ctx, const float* y4, const float*
  * separation/backends.py:358.  w_packed = weights (BatchNorm folded, scaled by a power of two 1/w_unscale)
  * pre-arranged in MFMA fragment order by audio_cut_amd.separation.conv_pack.pack_conv3x3
  * ([C_out/48][C_in/16][5][hi,lo][3][64] fragments of 8 f16).  C_in % 16 == 0, C_out % 48 == 0, H % 8 == 0,
- * W % 32 == 0.  out = conv(x) * w_unscale + bias[c], followed by ReLU when relu != 0. */
+ * W % 32 == 0.  out = conv(x) * w_unscale + bias[c], followed by ReLU when relu != 0.
+ *
+ * "amax" (every split-float16 kernel below takes the pair): in_amax [B] float32 = max |x| of each batch item of the INPUT
+ * tensor, as written by the kernel that produced it; the activations are scaled by the power of two that puts that maximum
+ * in [2^14, 2^15) before the float16 split (undone exactly in the epilogue), so the low part stays a normal float16 down to
+ * 2^-17 of the item's peak and the representation error is max(2^-22 |x|, 2^-40 max|x|) instead of max(2^-22 |x|, 3e-8):
+ * float32-class relative accuracy for quiet items and for decays into silence, and no saturation at 65504.
+ * out_amax [B] (zeroed by the caller before the launch) receives max |out| per item by ordered-bits atomicMax.
+ * Either may be NULL: no scaling (the pre-ABI-2 behaviour) / no reduction. */
 int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                     int C_out, int H, int W, float w_unscale, int relu, void* stream);
+                     int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
 
 /* The graph's first (4 -> g) and last (g -> 4) 1x1 convolutions (Conv nodes at the two ends of the graph run at
  * separation/backends.py:358; oracle/separator.py:78,94): float32 FMAs at streaming rate.
@@ -210,7 +194,17 @@ int ac_conv1x1_small(ac_ctx* ctx, const float* x, const float* w, const float* b
  * audio_cut_amd.separation.conv_pack.pack_linear ([N/BN][K/32][hi,lo][BN/16][64] fragments of 8 f16, BN = 192 when
  * N % 192 == 0 else 96).  M % 128 == 0, K % 32 == 0, N % 96 == 0. */
 int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
-                        const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale, void* stream);
+                        const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale,
+                        const float* in_amax, float* out_amax /* per item = per C*T rows; need (C*T) % 128 == 0 */, void* stream);
+
+/* Both TDF layers + residual of a block at the deep levels (F = 384 / 192 / 96, bottleneck Hd = F / 8 <= 48: too narrow for
+ * ac_tdf_linear_f16x3), one kernel, exact float32 on v_mfma_f32_16x16x4_f32 (same graph nodes as ac_tdf_linear_f16x3):
+ *   y[m][n] = x[m][n] + relu(scale2[c] * sum_j relu(scale1[c] * sum_f x[m][f] w1[j][f] + shift1[c]) w2[n][j] + shift2[c])
+ * w1_packed / w2_packed from conv_pack.pack_tdf_small.  M % 32 == 0, F % 16 == 0, x != y.  out_amax as above (needs
+ * (C * T) % 32 == 0); no in_amax: nothing is split. */
+int ac_tdf_small_fused(ac_ctx* ctx, const float* x, const void* w1_packed, const void* w2_packed, const float* scale1,
+                       const float* shift1, const float* scale2, const float* shift2, float* y, long long M, int F, int Hd,
+                       int T, int C, float* out_amax, void* stream);
 
 /* The U-Net's 2x2 / stride-2 resampling layers (Conv stride 2 / ConvTranspose stride 2 + BatchNormalization + Relu
  * (+ Mul with the encoder skip) nodes of the graph run at separation/backends.py:358; oracle/separator.py:85-91),
@@ -221,9 +215,9 @@ int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const
  * W[(co,dy,dx)][ci] (up), zero padded to N % 96 == 0, K % 32 == 0.  Pixels per image on the GEMM's M axis
  * ((H/2)*(W/2) down, H*W up) % 128 == 0; W % 4 == 0; down: H even, C_in % 8 == 0; up: 4*C_out % 96 == 0. */
 int ac_down2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
-                    int H, int W, float w_unscale, void* stream);
+                    int H, int W, float w_unscale, const float* in_amax, float* out_amax, void* stream);
 int ac_up2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out, int B,
-                  int C_in, int C_out, int H, int W, float w_unscale, void* stream);
+                  int C_in, int C_out, int H, int W, float w_unscale, const float* in_amax, float* out_amax, void* stream);
 
 /* ---- multi-feature detector branch (pure_vocal_pause_detector.py:410-459,937-1018) ----------- */
 
@@ -292,22 +286,24 @@ int ac_pack_pcm24(ac_ctx* ctx, const float* x, int64_t n, unsigned char* out, vo
 
 /* ac_conv3x3_f16x3 with the graph's first 1x1 convolution (spec [B][C0][H][W], C0 <= 4, w1 [C_in][C0], b1 [C_in], + ReLU;
  * the first Conv + BatchNormalization + Relu nodes at separation/backends.py:358) fused into its loader: the C_in-channel
- * tensor is generated per staged pixel with ac_conv1x1_small's arithmetic (bit-identical) and never written to HBM. */
+ * tensor is generated per staged pixel with ac_conv1x1_small's arithmetic (bit-identical) and never written to HBM.
+ * spec_amax [B] = max |spec| per item (ac_mdx_stft); the generated tensor's maximum is bounded by
+ * spec_amax * amax_gain + amax_offs with amax_gain = max_c sum_j |w1[c][j]|, amax_offs = max_c |b1[c]| (host constants). */
 int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,
                            const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W, float w_unscale,
-                           int relu, void* stream);
+                           int relu, const float* spec_amax, float amax_gain, float amax_offs, float* out_amax, void* stream);
 
 /* ac_conv3x3_f16x3 with 96 output channels per workgroup (C_in % 16 == 0, C_out % 96 == 0; weights packed by
  * conv_pack.pack_conv3x3_w96: 8-channel stages, tap 8 of four consecutive stages in one k-step).  Same replaced graph nodes
  * (Conv 3x3 + folded BatchNormalization + Relu of Kim_Vocal_1.onnx, reference backends.py:358), same arithmetic; every staged
  * activation byte feeds twice the MFMAs. */
 int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                         int C_out, int H, int W, float w_unscale, int relu, void* stream);
+                         int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
 
 /* The 8-channel-stage kernel with 48 output channels per workgroup, three workgroups per CU (C_in % 16 == 0, C_out % 48 == 0;
  * conv_pack.pack_conv3x3_w96(w, cob=48)): the layers ac_conv3x3_f16x3_w96 cannot take. */
 int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                        int C_out, int H, int W, float w_unscale, int relu, void* stream);
+                        int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
 
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 

@@ -231,7 +231,7 @@ def test_c5_long_form_round_trip_and_determinism(hip_ctx):
     from audio_cut_amd.utils.gpu_pipeline import chunk_schedule
 
     class _Identity(torch.nn.Module):
-        def forward_tf(self, x):
+        def forward_tf(self, x, spec_amax=None):
             return x
 
     n = 1800 * SR
@@ -374,11 +374,13 @@ def test_c2_full_size_track_against_oracle_fixture(hip_ctx, golden_dir, fixture,
     np.testing.assert_allclose(rms, g["vocal_rms_per_second"], rtol=1e-4, atol=1e-4 * peak)
 
 
-def test_threshold_crossing_sensitivity_is_bounded(hip_ctx, golden_dir):
-    """The one live-soak track (of 21) whose result is not index-identical to the oracle's: its manifest cuts, labels and pause
-    cut points are, and the guard boundaries differ in at most one place by at most two samples - the quiet guard's
-    "first sample under the floor" on a slow decay, moved by the 6e-6 stem difference.  This pins that
-    characterisation: a wider deviation is a regression, an exact match is welcome."""
+def test_soak_track_on_a_threshold_crossing_is_exact(hip_ctx, golden_dir):
+    """The one round-1 live-soak track (of 21) that was NOT index-identical to the oracle: a sine-burst / silence track whose guard
+    boundary #8 is the quiet guard's "first sample under the floor" on a slow decay into a silent stretch.  Round 1's split-f16
+    kernels carried an absolute error floor of 2^-25 per activation (the float16 low part went subnormal below 6e-2), so the
+    quiet tail of the decay lost its relative precision and the crossing moved by two samples (1947295 vs 1947297).  With the
+    per-item activation scale (include/audiocut_hip.h "amax") the stems are float32-class in the quiet region too and every
+    index is exact."""
     from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
     from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
     from audio_cut_amd.separation.backends import MDX23HipBackend
@@ -388,15 +390,15 @@ def test_threshold_crossing_sensitivity_is_bounded(hip_ctx, golden_dir):
     backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=17), ctx=hip_ctx, max_items_per_forward=32)
     backend.load_model()
     res = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend)).split_track(mix)
+    voc = res["vocal_track"]
+    stem_err = float(np.max(np.abs(voc[: 4 * SR: 7] - g["vocal_head"]))) / float(g["vocal_peak"])
+    got, want = res["sample_boundaries"], g["sample_boundaries"].tolist()
+    print(f"soak track: stem error {stem_err:.2e} of peak, moved boundaries {[(a, b) for a, b in zip(got, want) if a != b]}")
+    assert got == want
     assert res["cuts_samples"] == g["cuts"].tolist()
     assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
     assert np.array_equal(np.asarray([p.cut_point for p in res["pauses"]]), g["pause_cut_points"])
-    got, want = res["sample_boundaries"], g["sample_boundaries"].tolist()
-    assert len(got) == len(want)
-    moved = [(a, b) for a, b in zip(got, want) if a != b]
-    assert len(moved) <= 1 and all(abs(a - b) <= 2 for a, b in moved), moved
-    voc = res["vocal_track"]
-    assert float(np.max(np.abs(voc[: 4 * SR: 7] - g["vocal_head"]))) / float(g["vocal_peak"]) < STEM_RTOL
+    assert stem_err < 3e-6
 
 
 def test_track_pipeline_matches_sequential_processing(hip_ctx):

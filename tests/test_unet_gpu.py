@@ -1,6 +1,4 @@
 """TFC-TDF U-Net (PyTorch-ROCm, folded BN, T-major layout) against a float64 CPU evaluation, block by block."""
-import copy
-
 import numpy as np
 import pytest
 import torch
@@ -9,6 +7,8 @@ from audio_cut_amd.separation.tfc_tdf import TfcTdfNet, TfcTdfSpec, synth_weight
 from audio_cut_amd.testing import signals
 from oracle import chunking as OC
 from oracle.separator import mdx_stft, unet_forward
+
+import unet_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -19,45 +19,39 @@ def test_unet_blocks_and_output_vs_float64(hip_ctx):
     mix = signals.c2_song(10.0, seed=4)
     batch, _, _ = OC.mdx_windows(mix)
     x = mdx_stft(batch[:1])[..., :64].contiguous()          # [1, 4, 3072, 64]: 64 frames keep the float64 CPU pass short
-    net = TfcTdfNet(w, spec).eval()
-    net64 = copy.deepcopy(net).double()
-    netg = TfcTdfNet(w, spec, hip=hip_ctx).to(hip_ctx.device).eval()    # product configuration: f16x3 MFMA convs + fused epilogues
+    netg = TfcTdfNet(w, spec, hip=hip_ctx).to(hip_ctx.device).eval()    # product: one HIP kernel per layer
     got, ref = {}, {}
-
-    def hook(store, name):
-        return lambda m, i, o: store.__setitem__(name, o.detach().double().cpu())
-
-    for n_, st in ((netg, got), (net64, ref)):
-        for i, b in enumerate(n_.enc):
-            b.register_forward_hook(hook(st, f"enc{i}"))
-        n_.bottleneck.register_forward_hook(hook(st, "bottleneck"))
-        for i, b in enumerate(n_.dec):
-            b.register_forward_hook(hook(st, f"dec{i}"))
-    yg = netg(x.to(hip_ctx.device)).double().cpu()
-    y64 = net64(x.double())
+    netg.block_tap = lambda name, t: got.__setitem__(name, t.detach().double().cpu())
+    try:
+        yg = netg(x.to(hip_ctx.device)).double().cpu()
+    finally:
+        netg.block_tap = None
+    y64 = unet_torch.forward(netg, x.double(), tap=lambda name, t: ref.__setitem__(name, t.detach().clone()))
     errs = {name: float((got[name] - r).abs().max() / r.abs().max()) for name, r in ref.items()}
     print("block errors vs float64 (relative to block peak):", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert set(errs) == {f"enc{i}" for i in range(5)} | {f"dec{i}" for i in range(5)} | {"bottleneck"}
     for name, err in errs.items():
         assert err < 1e-3, (name, err)                      # every level, relative to that block's own peak
     out_err = float((yg - y64).abs().max() / y64.abs().max())
     print(f"output error vs float64: {out_err:.2e}")
     assert out_err < 1e-5           # float32-class: the split-f16 convs keep 22 mantissa bits
-    hip_ctx.conv_impl = "miopen"                                            # float32 MIOpen convs + rocBLAS TDF: plain float32 accuracy
-    hip_ctx.tdf_impl = "rocblas"
-    hip_ctx.resample_impl = "gemm"
-    try:
-        y32 = netg(x.to(hip_ctx.device)).double().cpu()
-    finally:
-        hip_ctx.conv_impl = "f16x3"
-        hip_ctx.tdf_impl = "f16x3"
-        hip_ctx.resample_impl = "f16x3"
-    assert float((y32 - y64).abs().max() / y64.abs().max()) < 1e-5
+    # the same folded graph in plain float32 through MIOpen / rocBLAS (tests/unet_torch.py): what "float32" itself delivers
+    y32 = unet_torch.forward(netg, x.to(hip_ctx.device)).double().cpu()
+    lib_err = float((y32 - y64).abs().max() / y64.abs().max())
+    print(f"MIOpen/rocBLAS float32 error vs float64: {lib_err:.2e}")
+    assert lib_err < 1e-5 and out_err < 4 * lib_err + 1e-6
     # the un-fused oracle graph (conv -> BN -> ReLU as separate float32 ops) agrees with the folded net
     yo = unet_forward(x, w).double()
     assert float((yo - y64).abs().max() / y64.abs().max()) < 1e-5
     # ONNX-shaped entry point == T-major entry point
     ytf = netg.forward_tf(x.transpose(-1, -2).contiguous().to(hip_ctx.device)).transpose(-1, -2).double().cpu()
     assert torch.equal(ytf, yg)
+    # no library path: a net without the HIP context, or a shape the kernels cannot tile, raises
+    from audio_cut_amd._native import NativeError
+    with pytest.raises(NativeError):
+        TfcTdfNet(w, spec).forward_tf(x.transpose(-1, -2).contiguous())
+    with pytest.raises(NativeError):
+        netg.forward_tf(torch.zeros(1, 4, 36, 3072, device=hip_ctx.device))
 
 
 def test_conv3x3_f16x3_kernel(hip_ctx):
@@ -148,57 +142,6 @@ def test_tdf_linear_f16x3_kernel(hip_ctx):
         hip_ctx.tdf_linear_f16x3(torch.zeros(1, 3, 5, 32, device=dev), wp, 96, sc, sh, 1.0)     # rows % 128 != 0: refused, not mis-tiled
 
 
-def test_fused_epilogues_match_the_unfused_torch_ops(hip_ctx):
-    """TfcTdfNet with the HIP epilogues (bias+ReLU, affine+ReLU(+residual), bias+ReLU*skip) == plain PyTorch elementwise ops."""
-    spec = TfcTdfSpec()
-    w = synth_weights(spec, seed=0)
-    g = torch.Generator().manual_seed(1)
-    x = (torch.randn(2, 4, 32, 3072, generator=g) * 3.0).to(hip_ctx.device)
-    plain = TfcTdfNet(w, spec).to(hip_ctx.device).eval()
-    fused = TfcTdfNet(w, spec, hip=hip_ctx).to(hip_ctx.device).eval()
-    hip_ctx.conv_impl = "miopen"        # same float32 MIOpen convs / rocBLAS GEMMs on both sides: only the epilogues differ
-    hip_ctx.tdf_impl = "rocblas"
-    hip_ctx.resample_impl = "miopen"
-    try:
-        a = plain.forward_tf(x); b = fused.forward_tf(x)
-    finally:
-        hip_ctx.conv_impl = "f16x3"
-        hip_ctx.tdf_impl = "f16x3"
-        hip_ctx.resample_impl = "f16x3"
-    assert float((a - b).abs().max() / a.abs().max()) < 2e-6
-    # the kernels themselves, on odd row counts
-    t = torch.randn(3, 5, 7, 12, device=hip_ctx.device); bias = torch.randn(5, device=hip_ctx.device)
-    sk = torch.randn_like(t); sc = torch.randn(5, device=hip_ctx.device)
-    assert torch.equal(hip_ctx.bias_relu_(t.clone(), bias), torch.relu(t + bias.view(1, -1, 1, 1)))
-    assert torch.equal(hip_ctx.bias_relu_mul_(t.clone(), bias, sk), torch.relu(t + bias.view(1, -1, 1, 1)) * sk)
-    ref = torch.relu(t * sc.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
-    assert torch.equal(hip_ctx.affine_relu_(t.clone(), sc, bias), ref)
-    assert torch.equal(hip_ctx.affine_relu_add(t.clone(), sc, bias, sk), sk + ref)
-
-
-def test_gemm_form_resampling_matches_strided_convs(hip_ctx):
-    """space-to-depth + GEMM (down) and GEMM + depth-to-space (up) against conv2d(stride 2) / conv_transpose2d(stride 2)."""
-    import torch.nn.functional as F
-    g = torch.Generator().manual_seed(2)
-    dev = hip_ctx.device
-    for c, h, w_ in ((48, 32, 64), (96, 16, 32), (240, 8, 12)):
-        x = torch.randn(3, c, h, w_, generator=g).to(dev)
-        wd = (torch.randn(c + 48, c, 2, 2, generator=g) / np.sqrt(4 * c)).to(dev)
-        bd = torch.randn(c + 48, generator=g).to(dev)
-        ref = F.relu(F.conv2d(x, wd, bd, stride=2))
-        x2 = hip_ctx.space_to_depth2x(x).view(3, 4 * c, (h // 2) * (w_ // 2))
-        got = hip_ctx.bias_relu_(torch.matmul(wd.permute(0, 2, 3, 1).reshape(c + 48, -1), x2).view(3, c + 48, h // 2, w_ // 2), bd)
-        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
-        co = max(48, c - 48)
-        wu = (torch.randn(c, co, 2, 2, generator=g) / np.sqrt(c)).to(dev)
-        bu = torch.randn(co, generator=g).to(dev)
-        skip = torch.randn(3, co, 2 * h, 2 * w_, generator=g).to(dev)
-        ref = F.relu(F.conv_transpose2d(x, wu, bu, stride=2)) * skip
-        y4 = torch.matmul(wu.permute(2, 3, 1, 0).reshape(-1, c), x.view(3, c, h * w_)).view(3, 4 * co, h, w_)
-        got = hip_ctx.depth_to_space2x_bias_relu_mul(y4, bu, skip)
-        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
-
-
 def test_fused_resampling_kernels_vs_float64(hip_ctx):
     """ac_down2x_f16x3 / ac_up2x_f16x3 (gather/scatter fused around the split-f16 MFMA GEMM) against float64 strided /
     transposed convolutions, on U-Net level shapes incl. the channel counts that need N / K zero padding (144, 240)."""
@@ -262,20 +205,142 @@ def test_first_conv_fused_into_the_3x3_loader_is_bit_identical(hip_ctx):
     ref = hip_ctx.conv3x3_f16x3(mid, wp, b3, 48, un, relu=True)
     got = hip_ctx.conv3x3_f16x3_first(spec, w1, b1, wp, b3, 48, un, relu=True)
     assert torch.equal(got, ref)
-    spec_net = TfcTdfSpec()
-    w = synth_weights(spec_net, seed=0)
-    net = TfcTdfNet(w, spec_net, hip=hip_ctx).to(dev).eval()
-    x = (torch.randn(1, 4, 32, 3072, generator=g) * 2.0).to(dev)
-    a = net.forward_tf(x)
-    hip_ctx.fuse_first_conv = False
-    try:
-        b = net.forward_tf(x)            # the unfused first 3x3 conv now runs the 8-channel-stage kernel: other summation order
-        hip_ctx.conv_wide = False
-        c = net.forward_tf(x)            # every conv on the 16-channel-stage kernel, the fused loader's order
-        hip_ctx.fuse_first_conv = True
-        d = net.forward_tf(x)
-    finally:
-        hip_ctx.fuse_first_conv, hip_ctx.conv_wide = True, True
-    assert torch.equal(c, d)
-    peak = float(a.abs().max())
-    assert float((a - b).abs().max()) / peak < 2e-6 and float((a - c).abs().max()) / peak < 2e-6
+    # with the per-item activation scale: the fused kernel scales by the BOUND of the generated tensor, the unfused pair by its
+    # measured maximum - the same values up to the float16 low parts' last bit
+    amax_spec = spec.abs().amax(dim=(1, 2, 3)).contiguous()
+    gain = float(w1.abs().sum(dim=(1, 2, 3)).max()); offs = float(b1.abs().max())
+    oa = torch.zeros(2, device=dev)
+    got2 = hip_ctx.conv3x3_f16x3_first(spec, w1, b1, wp, b3, 48, un, relu=True, spec_amax=amax_spec, amax_gain=gain, amax_offs=offs, out_amax=oa)
+    assert float(mid.amax()) <= float((amax_spec * gain + offs).max())
+    ref2 = hip_ctx.conv3x3_f16x3(mid, wp, b3, 48, un, relu=True, in_amax=mid.abs().amax(dim=(1, 2, 3)).contiguous())
+    assert float((got2 - ref2).abs().max() / ref2.abs().max()) < 1e-6
+    assert torch.equal(oa, got2.abs().amax(dim=(1, 2, 3)))
+
+
+def _elementwise_error(y: torch.Tensor, ref64: torch.Tensor, scale64: torch.Tensor) -> float:
+    """max over elements of |y - ref| / (sum |x| |w| + |b|): the backward-error scale of each output element itself, so a
+    quiet region is held to the same relative accuracy as a loud one (unlike an error relative to the tensor's peak)."""
+    return float(((y.double() - ref64).abs() / scale64.clamp_min(1e-300)).max())
+
+
+def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
+    """The per-item activation scale (include/audiocut_hip.h, "amax"): every split-float16 kernel is fed inputs from 1e-6 to 1e6
+    (past the float16 range: nothing saturates), uniform and with a 1e-4 decay along the time axis inside one item, and its
+    ELEMENT-WISE error against float64 must stay within 4x of what a true float32 evaluation (PyTorch CPU float32) of the same
+    layer delivers.  Without the scale the 1e-6 and decaying cases are 2-4 orders of magnitude worse (the low float16 part is
+    a subnormal) and the 1e6 case clips.  out_amax must be the exact per-item maximum of the result."""
+    import torch.nn.functional as F
+    from audio_cut_amd.separation.conv_pack import pack_conv3x3, pack_conv3x3_w96, pack_linear
+    g = torch.Generator().manual_seed(11)
+    dev = hip_ctx.device
+    mags = (1e-6, 1e-3, 1.0, 3.0e2, 6.0e4, 1.0e6)
+    worst = {}
+
+    def check(name, run, ref_fn, x, has_bias_scale):
+        """run(x_dev, in_amax, out_amax) -> y ; ref_fn(x, dtype) -> (y, scale) on the CPU in `dtype`."""
+        for mag in mags:
+            for decay in (False, True):
+                xm = x * mag
+                if decay:       # item 0 keeps its level, item 1 falls by 1e-4 along H (time): a decay into silence inside one item
+                    ramp = torch.logspace(0, -4, x.shape[2], dtype=torch.float32).view(1, 1, -1, 1)
+                    xm = torch.cat([xm[:1], xm[1:] * ramp], dim=0)
+                ia = xm.abs().amax(dim=(1, 2, 3)).contiguous().to(dev)
+                oa = torch.zeros(x.shape[0], device=dev)
+                y = run(xm.to(dev), ia, oa)
+                assert torch.equal(oa, y.abs().amax(dim=(1, 2, 3))), (name, mag)
+                ref64, scale64 = ref_fn(xm.double(), torch.float64)
+                y32, _ = ref_fn(xm, torch.float32)
+                e16 = _elementwise_error(y.cpu(), ref64, scale64)
+                e32 = _elementwise_error(y32, ref64, scale64)
+                worst[name] = max(worst.get(name, 0.0), e16 / max(e32, 1e-12))
+                assert e16 <= 4.0 * e32 + 2.0 ** -24, (name, mag, decay, e16, e32)
+
+    # --- 3x3 convs: 16-channel-stage kernel, 96-channel and 48-channel 8-channel-stage kernels
+    for ci, co, h, w_, kind in ((48, 48, 16, 64, "plain"), (96, 96, 16, 64, "w96"), (48, 48, 16, 64, "s8"), (144, 144, 8, 32, "s8")):
+        x = torch.randn(2, ci, h, w_, generator=g)
+        wt = torch.randn(co, ci, 3, 3, generator=g) / np.sqrt(9 * ci)
+        bias = torch.zeros(co)              # bias-free like the synthetic net's convs: the output scales with the input
+        if kind == "plain":
+            packed, un = pack_conv3x3(wt.numpy()); fn = hip_ctx.conv3x3_f16x3
+        else:
+            packed, un = pack_conv3x3_w96(wt.numpy(), 96 if kind == "w96" else 48)
+            fn = hip_ctx.conv3x3_f16x3_w96 if kind == "w96" else hip_ctx.conv3x3_f16x3_s8
+        wp = torch.from_numpy(packed.view(np.int16)).to(dev); bd = bias.to(dev)
+
+        def ref(xx, dt, wt=wt):
+            y = F.relu(F.conv2d(xx, wt.to(dt), None, padding=1))
+            return y.double(), F.conv2d(xx.abs().double(), wt.abs().double(), None, padding=1)
+        check(f"conv_{kind}_{ci}", lambda xd, ia, oa, fn=fn, wp=wp, bd=bd, co=co, un=un: fn(xd, wp, bd, co, un, relu=True, in_amax=ia, out_amax=oa),
+              ref, x, False)
+    # --- TDF layer (GEMM over the last axis + affine + ReLU + residual)
+    for (c, t, k, n) in ((48, 8, 384, 96), (48, 8, 96, 384)):
+        x = torch.randn(2, c, t, k, generator=g)
+        wt = torch.randn(n, k, generator=g) / np.sqrt(k)
+        sc = torch.rand(c, generator=g) + 0.5; sh = torch.zeros(c)
+        packed, un = pack_linear(wt.numpy())
+        wp = torch.from_numpy(packed.view(np.int16)).to(dev)
+
+        def ref(xx, dt, wt=wt, sc=sc):
+            y = F.relu(F.linear(xx, wt.to(dt)) * sc.to(dt).view(1, -1, 1, 1))
+            return y.double(), F.linear(xx.abs().double(), wt.abs().double()) * sc.double().view(1, -1, 1, 1)
+        check(f"tdf_{k}x{n}", lambda xd, ia, oa, wp=wp, n=n, sc=sc, sh=sh, un=un: hip_ctx.tdf_linear_f16x3(xd, wp, n, sc.to(dev), sh.to(dev), un, in_amax=ia, out_amax=oa),
+              ref, x, False)
+    # --- 2x2 down / up sampling
+    c, h, w_ = 48, 16, 64
+    x = torch.randn(2, c, h, w_, generator=g)
+    wd = torch.randn(c + 48, c, 2, 2, generator=g) / np.sqrt(4 * c)
+    packed, un = pack_linear(wd.numpy().reshape(c + 48, -1), bn=96)
+    wpd = torch.from_numpy(packed.view(np.int16)).to(dev); zb = torch.zeros(c + 48, device=dev)
+
+    def ref_dn(xx, dt):
+        return F.relu(F.conv2d(xx, wd.to(dt), None, stride=2)).double(), F.conv2d(xx.abs().double(), wd.abs().double(), None, stride=2)
+    check("down", lambda xd, ia, oa: hip_ctx.down2x_f16x3(xd, wpd, zb, c + 48, un, in_amax=ia, out_amax=oa), ref_dn, x, False)
+    c2 = 96
+    x = torch.randn(2, c2, 8, 64, generator=g)
+    wu = torch.randn(c2, c2 - 48, 2, 2, generator=g) / np.sqrt(c2)
+    packed, un2 = pack_linear(wu.numpy().transpose(1, 2, 3, 0).reshape(-1, c2), bn=96)
+    wpu = torch.from_numpy(packed.view(np.int16)).to(dev); zb2 = torch.zeros(c2 - 48, device=dev)
+
+    def ref_up(xx, dt):
+        return F.relu(F.conv_transpose2d(xx, wu.to(dt), None, stride=2)).double(), F.conv_transpose2d(xx.abs().double(), wu.abs().double(), None, stride=2)
+    check("up", lambda xd, ia, oa: hip_ctx.up2x_f16x3(xd, wpu, zb2, c2 - 48, un2, in_amax=ia, out_amax=oa), ref_up, x, False)
+    print("worst element-wise error relative to a float32 evaluation:", {k: f"{v:.2f}x" for k, v in worst.items()})
+    # and what the scale buys: the same 1e-6 input WITHOUT it is orders of magnitude off element-wise
+    x = torch.randn(2, 48, 16, 64, generator=g) * 1e-6
+    wt = torch.randn(48, 48, 3, 3, generator=g) / np.sqrt(9 * 48)
+    packed, un = pack_conv3x3_w96(wt.numpy(), 48)
+    wp = torch.from_numpy(packed.view(np.int16)).to(dev)
+    ref64 = F.relu(F.conv2d(x.double(), wt.double(), None, padding=1)); sc64 = F.conv2d(x.abs().double(), wt.abs().double(), None, padding=1)
+    y0 = hip_ctx.conv3x3_f16x3_s8(x.to(dev), wp, torch.zeros(48, device=dev), 48, un, relu=True).cpu()
+    y1 = hip_ctx.conv3x3_f16x3_s8(x.to(dev), wp, torch.zeros(48, device=dev), 48, un, relu=True,
+                                  in_amax=x.abs().amax(dim=(1, 2, 3)).to(dev)).cpu()
+    assert _elementwise_error(y0, ref64, sc64) > 100 * _elementwise_error(y1, ref64, sc64)
+
+
+def test_tdf_small_fused_kernel(hip_ctx):
+    """ac_tdf_small_fused (both narrow TDF layers + residual of the deep levels, exact float32 on v_mfma_f32_16x16x4_f32)
+    against float64 on the three shapes the U-Net has (F = 384 / 192 / 96, bottleneck 48 / 24 / 12), asymmetric weights, and
+    the per-item output maximum."""
+    import torch.nn.functional as F
+    from audio_cut_amd.separation.conv_pack import pack_tdf_small
+    g = torch.Generator().manual_seed(9)
+    dev = hip_ctx.device
+    for (b, c, t, f) in ((2, 192, 32, 384), (2, 240, 16, 192), (3, 288, 8, 96), (1, 4, 8, 32)):
+        hd = f // 8
+        x = torch.randn(b, c, t, f, generator=g) * 2
+        w1 = torch.randn(hd, f, generator=g) / np.sqrt(f); w2 = torch.randn(f, hd, generator=g) / np.sqrt(hd)
+        s1 = torch.rand(c, generator=g) + 0.5; b1 = torch.randn(c, generator=g) * 0.3
+        s2 = torch.rand(c, generator=g) + 0.5; b2 = torch.randn(c, generator=g) * 0.3
+        p1, p2 = pack_tdf_small(w1.numpy(), w2.numpy())
+        oa = torch.zeros(b, device=dev)
+        y = hip_ctx.tdf_small_fused(x.to(dev), torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev), hd, s1.to(dev), b1.to(dev),
+                                    s2.to(dev), b2.to(dev), out_amax=oa)
+        v = lambda a: a.double().view(1, -1, 1, 1)
+        xd = x.double()
+        h = F.relu(F.linear(xd, w1.double()) * v(s1) + v(b1))
+        ref = xd + F.relu(F.linear(h, w2.double()) * v(s2) + v(b2))
+        assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-6, (b, c, t, f)
+        assert torch.equal(oa, y.abs().amax(dim=(1, 2, 3)))
+    with pytest.raises(Exception):
+        hip_ctx.tdf_small_fused(torch.zeros(1, 3, 5, 96, device=dev), torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev), 12,
+                                s1.to(dev), b1.to(dev), s2.to(dev), b2.to(dev))           # rows % 32 != 0: refused
