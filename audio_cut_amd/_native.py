@@ -450,12 +450,13 @@ class Context:
     # -- MDX23 ---------------------------------------------------------------------------------------
     def mdx_stft(self, track: torch.Tensor, chunk_start: torch.Tensor, chunk_len: torch.Tensor,
                  win_index: torch.Tensor, out: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`amax` [n_items] float32, zeroed by the caller: receives max |spectrogram| per item (the first conv's activation scale)."""
+        """`amax` [n_items, 32] float32, zeroed by the caller: receives max |spectrogram| per item and block of 8 frames (the first
+        conv's time-local activation scale)."""
         self._chk_f32(track)
         n_items = chunk_start.numel()
         if out is None:
             out = torch.empty((n_items, 4, 256, 3072), dtype=torch.float32, device=self.device)
-        _, pa = self._amax_args(n_items, None, amax)
+        _, pa = self._amax_args(n_items, None, amax, 256, 256)
         _check(self.lib.ac_mdx_stft(self._h, _ptr(track), track.numel(), _ptr(chunk_start), _ptr(chunk_len), _ptr(win_index),
                                     n_items, _ptr(out), pa, _stream()))
         return out
@@ -488,10 +489,16 @@ class Context:
         return out
 
     # -- U-Net layers (NCHW float32; `in_amax` / `out_amax`: per-item max |x| of the input / output tensor, include/audiocut_hip.h) --
-    def _amax_args(self, b: int, in_amax: Optional[torch.Tensor], out_amax: Optional[torch.Tensor]):
-        for t in (in_amax, out_amax):
-            if t is not None and (t.dtype != torch.float32 or t.numel() != b or not t.is_contiguous() or t.device != self.device):
-                raise NativeError("amax tensors must be contiguous float32 [batch] on the context's device")
+    AMAX_ROWS = 8       # AC_AMAX_ROWS: rows of the time axis per amax block
+
+    def _amax_args(self, b: int, in_amax: Optional[torch.Tensor], out_amax: Optional[torch.Tensor], h_in: int, h_out: int):
+        """amax tensors are float32 [batch, H / 8] (H = the tensor's time axis): max |x| per item and block of 8 rows."""
+        for t, h in ((in_amax, h_in), (out_amax, h_out)):
+            if t is None:
+                continue
+            if h % self.AMAX_ROWS or t.dtype != torch.float32 or t.numel() != b * (h // self.AMAX_ROWS) or not t.is_contiguous() \
+                    or t.device != self.device:
+                raise NativeError(f"amax tensors must be contiguous float32 [batch, H / 8] on the context's device (H = {h})")
         return _ptr(in_amax), _ptr(out_amax)
 
     def _conv3x3(self, fn, name: str, x, w_packed, bias, c_out, w_unscale, relu, out, in_amax, out_amax) -> torch.Tensor:
@@ -500,7 +507,7 @@ class Context:
         b, c_in, h, w = x.shape
         if out is None:
             out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
-        pi, po = self._amax_args(b, in_amax, out_amax)
+        pi, po = self._amax_args(b, in_amax, out_amax, h, h)
         _check(fn(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c_in, c_out, h, w, float(w_unscale), int(relu), pi, po,
                   _stream()))
         return out
@@ -537,7 +544,7 @@ class Context:
         if w1.shape[1] != c0 or not w1.is_contiguous():
             raise NativeError("conv3x3_f16x3_first: w1 must be [C_in, C0(,1,1)] contiguous")
         out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=self.device)
-        pi, po = self._amax_args(b, spec_amax, out_amax)
+        pi, po = self._amax_args(b, spec_amax, out_amax, h, h)
         _check(self.lib.ac_conv3x3_f16x3_first(self._h, _ptr(spec), _ptr(w1), _ptr(b1), _ptr(w_packed), _ptr(bias), _ptr(out), b, c0,
                                                w1.shape[0], c_out, h, w, float(w_unscale), int(relu), pi, float(amax_gain),
                                                float(amax_offs), po, _stream()))
@@ -554,7 +561,7 @@ class Context:
         out = torch.empty((b, c, t, n_out), dtype=torch.float32, device=self.device)
         if resid is not None and (resid.shape != out.shape or not resid.is_contiguous() or resid.dtype != torch.float32):
             raise NativeError("tdf_linear_f16x3: residual must match the output")
-        pi, po = self._amax_args(b, in_amax, out_amax)
+        pi, po = self._amax_args(b, in_amax, out_amax, t, t)
         _check(self.lib.ac_tdf_linear_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(resid), _ptr(out),
                                             b * c * t, n_out, k, t, c, float(w_unscale), pi, po, _stream()))
         return out
@@ -568,7 +575,7 @@ class Context:
             raise NativeError("tdf_small_fused expects a contiguous float32 NCHW tensor")
         b, c, t, f = x.shape
         out = torch.empty_like(x)
-        _, po = self._amax_args(b, None, out_amax)
+        _, po = self._amax_args(b, None, out_amax, t, t)
         _check(self.lib.ac_tdf_small_fused(self._h, _ptr(x), _ptr(w1_packed), _ptr(w2_packed), _ptr(scale1), _ptr(shift1), _ptr(scale2),
                                            _ptr(shift2), _ptr(out), b * c * t, f, int(hidden), t, c, po, _stream()))
         return out
@@ -592,7 +599,7 @@ class Context:
             raise NativeError("down2x_f16x3 expects a contiguous float32 NCHW tensor")
         b, c, h, w = x.shape
         out = torch.empty((b, c_out, h // 2, w // 2), dtype=torch.float32, device=self.device)
-        pi, po = self._amax_args(b, in_amax, out_amax)
+        pi, po = self._amax_args(b, in_amax, out_amax, h, h // 2)
         _check(self.lib.ac_down2x_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), b, c, c_out, h, w, float(w_unscale),
                                         pi, po, _stream()))
         return out
@@ -607,7 +614,7 @@ class Context:
         out = torch.empty((b, c_out, 2 * h, 2 * w), dtype=torch.float32, device=self.device)
         if skip is not None and (skip.shape != out.shape or not skip.is_contiguous() or skip.dtype != torch.float32):
             raise NativeError("up2x_f16x3: skip must match the output")
-        pi, po = self._amax_args(b, in_amax, out_amax)
+        pi, po = self._amax_args(b, in_amax, out_amax, h, 2 * h)
         _check(self.lib.ac_up2x_f16x3(self._h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(skip), _ptr(out), b, c, c_out, h, w,
                                       float(w_unscale), pi, po, _stream()))
         return out

@@ -65,18 +65,24 @@ __device__ inline float wave_max_f32(float v) {
     return v;
 }
 
-// ---- per-item activation scale of the split-f16 MFMA kernels -------------------------------------------------
+// ---- time-local activation scale of the split-f16 MFMA kernels ----------------------------------------------------
 // x = xh + xl with xh = f16(x * s), xl = f16(x * s - xh): without s the low part is a float16 subnormal for |x| < 6e-2 and
 // the pair carries an ABSOLUTE error floor of 2^-25 however small the tensor is (decays into silence lose their relative
-// precision).  Every kernel that writes a tensor a split-f16 kernel reads therefore also reduces max|x| per batch item into
-// `amax[item]` (one ordered-bits atomicMax per wave); the reader scales by the power of two that puts that maximum in
-// [2^14, 2^15) and folds the inverse into its epilogue.  Power-of-two scaling is exact, so values whose low part is a normal
-// float16 either way round identically; the floor becomes max|x| * 2^-40, and nothing saturates below 2^127.
-__device__ inline float ac_act_scale(const float* __restrict__ amax, int item, float gain, float offs, float* inv) {
+// precision, which is where the quiet guard decides).  Every kernel that writes a tensor a split-f16 kernel reads therefore
+// also reduces max|x| per (batch item, block of AC_AMAX_ROWS rows of the time axis H) into `amax[item][H / 8]` (ordered-bits
+// atomicMax, one per wave and block); a reader takes the maximum over the blocks its tile touches, scales by the power of
+// two that puts it in [2^14, 2^15) and folds the inverse into its epilogue.  Power-of-two scaling is exact, so values whose
+// low part is a normal float16 either way round identically; the floor becomes 2^-40 of the LOCAL maximum (a silent stretch
+// between two loud passages keeps float32-class relative accuracy), and nothing saturates below 2^127.
+#define AC_AMAX_ROWS 8
+// amax_item = amax + item * n_blocks (or NULL: no scaling); blocks b0..b1 inclusive, already clamped; all arguments wave-uniform
+__device__ inline float ac_act_scale(const float* __restrict__ amax_item, int b0, int b1, float gain, float offs, float* inv) {
     float s = 1.f;
     *inv = 1.f;
-    if (amax) {
-        const float a = amax[item] * gain + offs;
+    if (amax_item) {
+        float a = 0.f;
+        for (int i = b0; i <= b1; ++i) a = fmaxf(a, amax_item[i]);
+        a = a * gain + offs;
         if (a > 0.f && a < 3.0e38f) {
             int e;
             (void)frexpf(a, &e);                    // a = m * 2^e, m in [0.5, 1)
@@ -86,7 +92,7 @@ __device__ inline float ac_act_scale(const float* __restrict__ amax, int item, f
             *inv = ldexpf(1.f, -e);
         }
     }
-    // `item` is uniform over the wave at every call site: keep the two factors in scalar registers
+    // wave-uniform by construction: keep the two factors in scalar registers
     *inv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(*inv)));
     s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
     return s;
@@ -96,6 +102,26 @@ __device__ inline void ac_amax_commit(float m, float* __restrict__ slot) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, AC_WAVE));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+}
+// the same per 32-lane half (lanes 0-31 -> slot_of_this_half as seen by lane 0, lanes 32-63 as seen by lane 32)
+__device__ inline void ac_amax_commit_halves(float m, float* __restrict__ slot_of_my_half) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, AC_WAVE));
+    if ((threadIdx.x & 31) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot_of_my_half), __float_as_uint(m));
+}
+// lanes may belong to different blocks: one reduction + atomic per distinct block id present in the wave (1-3 in practice)
+__device__ inline void ac_amax_commit_blocks(float m, int blk, float* __restrict__ slots) {
+    unsigned long long todo = __ballot(1);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __builtin_amdgcn_readlane(blk, leader);
+        const bool mine = blk == b;
+        float v = mine ? m : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, AC_WAVE));
+        if ((int)(threadIdx.x & 63) == leader && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(slots + b), __float_as_uint(v));
+        todo &= ~__ballot(mine);
+    }
 }
 
 // Block-wide sum of doubles for blockDim.x == 256 (4 waves); result valid in every thread.

@@ -94,10 +94,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     const int n_cb = C_in / CV_CB;
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * (FIRST ? C0 : C_in) * plane;
-    // per-item power-of-two activation scale (ac_common.h).  FIRST: in_amax is max|spectrogram|; the tensor that is split is the
+    // time-local power-of-two activation scale (ac_common.h).  FIRST: in_amax is max|spectrogram|; the tensor that is split is the
     // generated relu(w1 x + b1), bounded by amax * max_c sum_j |w1[c][j]| + max_c |b1[c]| (amax_gain, amax_offs from the host)
     float act_inv;
-    const float act_s = ac_act_scale(in_amax, b, amax_gain, amax_offs, &act_inv);
+    const int n_blk = H / AC_AMAX_ROWS, by = y0 / AC_AMAX_ROWS;          // the patch covers rows y0 - 1 .. y0 + 8 = row blocks by - 1 .. by + 1
+    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * n_blk : nullptr, by > 0 ? by - 1 : 0, by + 1 < n_blk ? by + 1 : n_blk - 1,
+                                     amax_gain, amax_offs, &act_inv);
     const float unscale = w_unscale * act_inv;
 
     f32x4 acc[CV_MT][4];
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         const float4 v = *reinterpret_cast<const float4*>(&s_out[line * CV_OUT_STRIDE + 4 * q4]);
         *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
     }
-    if (out_amax) ac_amax_commit(vmax, out_amax + b);
+    if (out_amax) ac_amax_commit(vmax, out_amax + (size_t)b * n_blk + by);
 }
 
 static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,

@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * C_in * plane;
     float act_inv;
-    const float act_s = ac_act_scale(in_amax, b, 1.f, 0.f, &act_inv);          // per-item power-of-two activation scale (ac_common.h)
+    // time-local power-of-two activation scale (ac_common.h): the patch covers rows y0 - 1 .. y0 + 8 = row blocks by - 1 .. by + 1
+    const int n_blk = H / AC_AMAX_ROWS, by = y0 / AC_AMAX_ROWS;
+    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * n_blk : nullptr, by > 0 ? by - 1 : 0, by + 1 < n_blk ? by + 1 : n_blk - 1,
+                                     1.f, 0.f, &act_inv);
     const float unscale = w_unscale * act_inv;
 
     f32x4 acc[W9_MT][4];
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
             *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
         }
     }
-    if (out_amax) ac_amax_commit(vmax, out_amax + b);
+    if (out_amax) ac_amax_commit(vmax, out_amax + (size_t)b * n_blk + by);
 }
 
 static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,

@@ -6,6 +6,9 @@
 // float32 accumulation in v_mfma_f32_16x16x32_f16) - float32-class products at the 16-bit MFMA rate.
 //
 // Workgroup: 256 threads = 2 x 2 waves, tile 128 rows x (32 * NT) columns, wave tile 64 x (16 * NT) (NT = 6 or 3).
+// The 128 rows of a tile are 16 channels x 8 consecutive time rows of one item (tile row r = channel r >> 3, time r & 7):
+// every row is its own contiguous F-vector, so the loads do not care, and a tile then lies in exactly ONE 8-row block of the
+// time axis - its activation scale is that block's maximum (ac_common.h), and it commits one output maximum.
 // K is walked in stages of 32: the x tile is loaded as full 128-byte row segments (float4 per lane), split to f16
 // hi/lo once and staged in LDS as [row][k] with an 96-byte row stride (conflict-free ds_read_b128 A fragments); the
 // weights arrive pre-split and pre-packed in B-fragment order (conv_pack.pack_linear) and go global -> LDS by DMA
@@ -55,13 +58,16 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int nb = wi % n_nblk, mb = wi / n_nblk;
     if (mb >= n_mblk) return;
-    const size_t m0 = (size_t)mb * GM_BM;
     const int n0 = nb * BN;
     const int n_stage = K / GM_BK;
-    // per-item power-of-two activation scale (ac_common.h); a 128-row tile lies inside one item ((C * T) % 128 == 0, checked on the host)
-    const int item = (int)(m0 / ((size_t)C * T));
+    // tile -> (item, group of 16 channels, block of 8 time rows); time blocks of one channel group are neighbours in the walk
+    const int n_blk = T / AC_AMAX_ROWS, n_cg = C / 16;
+    const int tb = mb % n_blk, cg = (mb / n_blk) % n_cg, item = mb / (n_blk * n_cg);
+    const size_t m_base = ((size_t)item * C + (size_t)cg * 16) * T + (size_t)tb * AC_AMAX_ROWS;      // global row of tile row 0
+    auto grow = [&](int r) -> size_t { return m_base + (size_t)(r >> 3) * T + (r & 7); };            // global row of tile row r
+    // time-local power-of-two activation scale (ac_common.h): the tile reads one row block of one item
     float act_inv;
-    const float act_s = ac_act_scale(in_amax, item, 1.f, 0.f, &act_inv);
+    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)item * n_blk : nullptr, tb, tb, 1.f, 0.f, &act_inv);
     const float unscale = w_unscale * act_inv;
 
     f32x4 acc[GM_MT][NT];
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     for (int i = 0; i < GM_A_ITERS; ++i) {
         const int e = tid + 256 * i;
         const int row = e >> 3, kq = e & 7;
-        a_ptr[i] = x + (m0 + row) * (size_t)K + 4 * kq;
+        a_ptr[i] = x + grow(row) * (size_t)K + 4 * kq;
         a_off[i] = row * GM_ASTRIDE + 4 * kq;
     }
     const f16x8* wbase = wpk + (size_t)nb * n_stage * BFRAGS;
@@ -146,9 +152,9 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     auto out_offset = [&](int m, int i, int& c) -> size_t {
         const int e = lane + 64 * i;
         const int row = e / ROW_F4, q4 = e - row * ROW_F4;
-        const size_t gm = m0 + wm * 64 + m * 16 + row;
-        c = (int)((gm / (size_t)T) % (size_t)C);
-        return gm * (size_t)N + n0 + wn * (16 * NT) + 4 * q4;
+        const int tr = wm * 64 + m * 16 + row;
+        c = cg * 16 + (tr >> 3);
+        return grow(tr) * (size_t)N + n0 + wn * (16 * NT) + 4 * q4;
     };
     if (RESID) {
 #pragma unroll
@@ -183,18 +189,17 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (out_amax) ac_amax_commit(vmax, out_amax + item);
+    if (out_amax) ac_amax_commit(vmax, out_amax + (size_t)item * n_blk + tb);
 }
 
 extern "C" int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
                                     const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale,
                                     const float* in_amax, float* out_amax, void* stream) {
     AC_REQUIRE(ctx && x && w_packed && scale && shift && y, "null pointer");
-    AC_REQUIRE(M > 0 && M % GM_BM == 0, "M % 128 == 0");
+    AC_REQUIRE(M > 0 && C > 0 && T > 0 && C % 16 == 0 && T % AC_AMAX_ROWS == 0 && M % ((long long)C * T) == 0,
+               "rows = items x C x T with C % 16 == 0 and T % 8 == 0 (a tile is 16 channels x 8 time rows)");
     AC_REQUIRE(K > 0 && K % GM_BK == 0, "K % 32 == 0");
     AC_REQUIRE(N > 0 && N % 96 == 0, "N % 96 == 0");
-    AC_REQUIRE(T > 0 && C > 0, "T, C > 0");
-    AC_REQUIRE((!in_amax && !out_amax) || ((long long)C * T) % GM_BM == 0, "per-item amax needs (C * T) % 128 == 0");
     const bool wide = (N % 192) == 0;
     const long long n_mblk = M / GM_BM;
     long long nblk = n_mblk * (N / (wide ? 192 : 96));

@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     const int p0 = (mb - b * tiles_per_img) * RS_BM;                         // first pixel of the tile inside its image
     const size_t plane_in = (size_t)H * W;
     const float* xb = x + (size_t)b * Ci * plane_in;
+    // time-local power-of-two activation scale (ac_common.h): the tile's 128 pixels cover input rows r0 .. r1
+    const int nb_in = H / AC_AMAX_ROWS, nb_out = (MODE ? 2 * H : (H >> 1)) / AC_AMAX_ROWS;
+    const int r0 = MODE ? p0 / W : 2 * (p0 / Wo), r1 = MODE ? (p0 + RS_BM - 1) / W : 2 * ((p0 + RS_BM - 1) / Wo) + 1;
     float act_inv;
-    const float act_s = ac_act_scale(in_amax, b, 1.f, 0.f, &act_inv);          // per-item power-of-two activation scale (ac_common.h)
+    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * nb_in : nullptr, r0 / AC_AMAX_ROWS, r1 / AC_AMAX_ROWS, 1.f, 0.f, &act_inv);
     const float unscale = w_unscale * act_inv;
 
     f32x4 acc[RS_MT][RS_NT];
@@ -175,11 +178,12 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     // ---- epilogues: D[row m = (lane >> 4) * 4 + r][col n = lane & 15]; strips are wave-private (LDS is in-order per wave)
     const int g = lane >> 4, px = lane & 15;
     __syncthreads();                     // every wave is done reading the stage buffers
-    float vmax = 0.f;
+    float* amax_slots = out_amax ? out_amax + (size_t)b * nb_out : nullptr;
     if (MODE == 0) {
         // down: NCHW output, pixels contiguous per channel.  Per n-tile: strip [16 n][64 m] -> 256-byte runs per channel.
         float* so = s_out + wave * 16 * OSTRIDE_DN;
         const size_t plane_out = (size_t)P;
+        float vmax = 0.f;
 #pragma unroll
         for (int n = 0; n < RS_NT; ++n) {
 #pragma unroll
@@ -203,6 +207,8 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
             }
             __builtin_amdgcn_wave_barrier();
         }
+        // every float4 of this lane = output pixels p0 + wm * 64 + 4 (lane & 15) .. + 3 of one output row (Wo % 4 == 0)
+        if (amax_slots) ac_amax_commit_blocks(vmax, ((p0 + wm * 64 + 4 * (lane & 15)) / Wo) / AC_AMAX_ROWS, amax_slots);
     } else {
         // up: column n = co * 4 + dy * 2 + dx.  Per m-tile: strip [16 m][48 n]; one float4 = 2 input pixels x (dx 0, 1) of one
         // (co, dy): 8 consecutive lanes write a 128-byte run of an output row.  The skip rows are fetched one strip ahead.
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 for (int i = 0; i < 3; ++i) { int nn; sk[(m + 1) & 1][i] = *reinterpret_cast<const float4*>(skip + out_offset(m + 1, i, nn)); }
             }
             __builtin_amdgcn_wave_barrier();
+            float vmax = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 int nn;
@@ -247,13 +254,14 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 float4 v = make_float4(fmaxf(a0.x * unscale + bv, 0.f), fmaxf(a0.y * unscale + bv, 0.f),
                                        fmaxf(a1.x * unscale + bv, 0.f), fmaxf(a1.y * unscale + bv, 0.f));
                 if (skip) { const float4 q = sk[m & 1][i]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
-                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 *reinterpret_cast<float4*>(out + o) = v;
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
+            // the lane's three float4 of this strip are output rows 2 yy + {0, 1} of input pixel pair (lane & 7): one 8-row block
+            if (amax_slots) ac_amax_commit_blocks(vmax, (2 * ((p0 + wm * 64 + m * 16 + 2 * (lane & 7)) / W)) / AC_AMAX_ROWS, amax_slots);
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (out_amax) ac_amax_commit(vmax, out_amax + b);
 }
 
 static int rs_launch(int mode, ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out,

@@ -105,9 +105,9 @@ def pack_conv3x3_w96(weight: np.ndarray, cob: int = 96) -> Tuple[np.ndarray, flo
     return out, 1.0 / scale
 
 
-def linear_tileable(n_out: int, k_in: int, rows: int) -> bool:
-    """shapes `ac_tdf_linear_f16x3` tiles: rows % 128 == 0, K % 32 == 0, N % 96 == 0."""
-    return rows % 128 == 0 and k_in % 32 == 0 and n_out % 96 == 0
+def linear_tileable(n_out: int, k_in: int, channels: int, t: int) -> bool:
+    """shapes `ac_tdf_linear_f16x3` tiles: C % 16 == 0, T % 8 == 0 (a tile is 16 channels x 8 time rows), K % 32 == 0, N % 96 == 0."""
+    return channels % 16 == 0 and t % 8 == 0 and k_in % 32 == 0 and n_out % 96 == 0
 
 
 def pack_linear(weight: np.ndarray, bn: int = 0) -> Tuple[np.ndarray, float]:

@@ -233,23 +233,27 @@ def _fold(weight: np.ndarray, bias: Optional[np.ndarray], w: Weights, bn_name: s
     return wf.astype(np.float32), bf.astype(np.float32)
 
 
+AMAX_ROWS = 8       # AC_AMAX_ROWS (csrc/ac_common.h): rows of the time axis per amax block
+
+
 class _AmaxTape:
-    """Per-forward scratch of per-item activation maxima (include/audiocut_hip.h, "amax"): one zeroed float32 [B] row per
-    tensor that a split-float16 kernel will read; the producing kernel reduces max |x| into it, the consumer derives its
-    power-of-two activation scale from it.  One allocation + one memset per forward."""
+    """Per-forward scratch of activation maxima (include/audiocut_hip.h, "amax"): one zeroed float32 [B, T / 8] array per tensor
+    that a split-float16 kernel will read; the producing kernel reduces max |x| per item and block of 8 time rows into it, the
+    consumer derives its time-local power-of-two activation scale from the blocks its tile touches.  One allocation + one
+    memset per forward."""
 
-    ROWS = 96
-
-    def __init__(self, batch: int, device: torch.device):
-        self._buf = torch.zeros((self.ROWS, batch), dtype=torch.float32, device=device)
+    def __init__(self, batch: int, t_full: int, n_tensors: int, device: torch.device):
+        self._batch = batch
+        self._buf = torch.zeros(n_tensors * batch * (t_full // AMAX_ROWS), dtype=torch.float32, device=device)
         self._next = 0
 
-    def new(self) -> torch.Tensor:
-        if self._next >= self.ROWS:
-            raise RuntimeError("amax tape exhausted")
-        row = self._buf[self._next]
-        self._next += 1
-        return row
+    def new(self, t: int) -> torch.Tensor:
+        n = self._batch * (t // AMAX_ROWS)
+        if t % AMAX_ROWS or self._next + n > self._buf.numel():
+            raise RuntimeError("amax tape exhausted or T % 8 != 0")
+        out = self._buf[self._next:self._next + n].view(self._batch, t // AMAX_ROWS)
+        self._next += n
+        return out
 
 
 class _Block(nn.Module):
@@ -318,7 +322,7 @@ class _Block(nn.Module):
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        ay = tape.new()
+        ay = tape.new(x.shape[2])
         if hasattr(self, f"cwq{j}"):
             y = hip.conv3x3_f16x3_w96(x, getattr(self, f"cwq{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True,
                                       in_amax=ax, out_amax=ay)
@@ -336,9 +340,9 @@ class _Block(nn.Module):
         deep levels (ac_tdf_small_fused)."""
         from .._native import NativeError
         rows = x.shape[0] * x.shape[1] * x.shape[2]
-        ay = tape.new()
-        if hasattr(self, "lwp0") and rows % 128 == 0 and (x.shape[1] * x.shape[2]) % 128 == 0:
-            ah = tape.new()
+        ay = tape.new(x.shape[2])
+        if hasattr(self, "lwp0") and x.shape[1] % 16 == 0 and x.shape[2] % 8 == 0:
+            ah = tape.new(x.shape[2])
             h = hip.tdf_linear_f16x3(x, self.lwp0, self.lw0.shape[0], self.ls0.view(-1), self.lb0.view(-1), self._l_unscale[0],
                                      in_amax=ax, out_amax=ah)
             y = hip.tdf_linear_f16x3(h, self.lwp1, self.lw1.shape[0], self.ls1.view(-1), self.lb1.view(-1), self._l_unscale[1], resid=x,
@@ -359,7 +363,7 @@ class _Block(nn.Module):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
             spec = x
-            ay = tape.new()
+            ay = tape.new(x.shape[2])
             x = hip.conv3x3_f16x3_first(spec, first[0], first[1], self.cwp0, self.cb0, self.cw0.shape[0], self._w_unscale[0], relu=True,
                                         spec_amax=ax, amax_gain=first[2], amax_offs=first[3], out_amax=ay)
             ax = ay
@@ -426,7 +430,7 @@ class TfcTdfNet(nn.Module):
         b, c, h, w = x.shape
         if h % 2 or w % 4 or ((h // 2) * (w // 2)) % 128 or c % 8:
             raise NativeError(f"down-sampling of shape {tuple(x.shape)} is not tileable by ac_down2x_f16x3")
-        ay = tape.new()
+        ay = tape.new(h // 2)
         y = hip.down2x_f16x3(x, getattr(self, f"ds_p{i}"), getattr(self, f"ds_b{i}"), getattr(self, f"ds_w{i}").shape[0],
                              self._rs_unscale[f"ds{i}"], in_amax=ax, out_amax=ay)
         return y, ay
@@ -438,7 +442,7 @@ class TfcTdfNet(nn.Module):
         c_out = getattr(self, f"us_w{i}").shape[1]
         if w % 4 or (h * w) % 128 or (4 * c_out) % 96:
             raise NativeError(f"up-sampling of shape {tuple(x.shape)} is not tileable by ac_up2x_f16x3")
-        ay = tape.new()
+        ay = tape.new(2 * h)
         y = hip.up2x_f16x3(x, getattr(self, f"us_p{i}"), getattr(self, f"us_b{i}"), c_out, self._rs_unscale[f"us{i}"], skip=skip,
                            in_amax=ax, out_amax=ay)
         return y, ay
@@ -453,7 +457,7 @@ class TfcTdfNet(nn.Module):
         """T-major call `[B, 4, T, F]` -> `[B, 4, T, F]`: the graph transposes right after its first 1x1
         conv and right before its last one (1x1 convs commute with the transpose), so the HIP STFT writes
         and the HIP iSTFT reads this layout directly and no transpose is ever materialised.
-        `spec_amax` [B] = max |spec| per item as ac_mdx_stft reduces it (computed here when absent)."""
+        `spec_amax` [B, T / 8] = max |spec| per item and block of 8 frames as ac_mdx_stft reduces it (computed here when absent)."""
         from .._native import NativeError
         hip = self.hip
         if hip is None or not spec_tf.is_cuda:
@@ -464,8 +468,8 @@ class TfcTdfNet(nn.Module):
         if not spec_tf.is_contiguous() or c0 > 4 or self.first_w.shape[0] > 64 or t % 8 or f % 32 or not hasattr(self.enc[0], "cwp0"):
             raise NativeError(f"spectrogram of shape {tuple(spec_tf.shape)} is not tileable by ac_conv3x3_f16x3_first")
         if spec_amax is None:
-            spec_amax = spec_tf.abs().amax(dim=(1, 2, 3)).contiguous()
-        tape = _AmaxTape(b, spec_tf.device)
+            spec_amax = spec_tf.abs().amax(dim=(1, 3)).view(b, t // AMAX_ROWS, AMAX_ROWS).amax(dim=2).contiguous()
+        tape = _AmaxTape(b, t, 6 * (2 * n + 1) + 2 * n, spec_tf.device)
         skips = []
         x, ax = spec_tf, spec_amax
         for i in range(n):
