@@ -100,9 +100,37 @@ def _lookup(tree: Dict[str, Any], path: str) -> Any:
 
 
 def get_config(path: str, default: Any = None) -> Any:
-    if path in _runtime:
-        return copy.deepcopy(_runtime[path])
-    # an override of a parent section or of a child key
+    """The reference's `set_runtime_config` writes the override INTO the config tree (`config_manager.py:497-509`), so an
+    override of a section (`{'segment_layout': {...}}`) replaces that subtree for every later child lookup, and an override
+    of a child key set afterwards lands inside it.  `_runtime` keeps insertion order: the last write that covers `path`
+    (the key itself, an ancestor, or descendants on top of either) wins."""
+    parts = path.split(".")
+    keys = list(_runtime)
+    # the most recently written ancestor section (or the key itself) that is a dict-valued override, if any
+    anc = [(keys.index(k), k) for k in (".".join(parts[:i]) for i in range(len(parts), 0, -1)) if k in _runtime]
+    if anc:
+        pos, key = max(anc)
+        rest = path[len(key) + 1:] if len(path) > len(key) else ""
+        node = _runtime[key]
+        sub = _lookup(node, rest) if rest else node
+        if rest and not isinstance(node, dict):
+            sub = _MISSING
+        value = copy.deepcopy(sub) if sub is not _MISSING else _MISSING
+        prefix = path + "."
+        later = {k[len(prefix):]: v for k, v in _runtime.items() if k.startswith(prefix) and keys.index(k) > pos}
+        exact_later = path in _runtime and keys.index(path) > pos
+        if exact_later:
+            value = copy.deepcopy(_runtime[path])
+        if later:
+            value = {} if value is _MISSING or not isinstance(value, dict) else value
+            for subkey, v in later.items():
+                tgt = value
+                sp = subkey.split(".")
+                for p_ in sp[:-1]:
+                    tgt = tgt.setdefault(p_, {})
+                tgt[sp[-1]] = copy.deepcopy(v)
+        return default if value is _MISSING else value
+    # an override of a child key only
     base = _lookup(DEFAULTS, path)
     prefix = path + "."
     children = {k[len(prefix):]: v for k, v in _runtime.items() if k.startswith(prefix)}
@@ -119,8 +147,9 @@ def get_config(path: str, default: Any = None) -> Any:
 
 
 def set_runtime_config(overrides: Dict[str, Any]) -> None:
-    """Dotted-key overrides (reference: config_manager.py:497-509)."""
+    """Dotted-key overrides (reference: config_manager.py:497-509).  A key written again moves to the end (last write wins)."""
     for k, v in (overrides or {}).items():
+        _runtime.pop(str(k), None)
         _runtime[str(k)] = v
 
 

@@ -4,9 +4,11 @@
 //    resampler is soxr_hq through librosa, which is not available offline, so the parity definition of this row is
 //    scipy.signal.resample_poly(x, up, down) (Kaiser(5.0) windowed sinc, half length 10 * max(up, down), zero padding),
 //    whose filter the host designs with the very scipy calls and hands over already scaled and front-padded.
-//  * ac_pack_pcm24: float32 [-1, 1] -> little-endian 24-bit PCM, round-to-nearest-even of x * 8388607 (libsndfile's
-//    normalised float -> PCM_24 conversion behind soundfile.write(subtype="PCM_24"), `audio_export.py:109-111`), clipped
-//    instead of wrapped; four samples (12 bytes) per thread.
+//  * ac_pack_pcm24: float32 [-1, 1] -> little-endian 24-bit PCM exactly as soundfile.write(subtype="PCM_24") produces it
+//    (`audio_export.py:109-111`).  python-soundfile switches libsndfile's clipping on (SFC_SET_CLIPPING), so the conversion
+//    is libsndfile pcm.c f2let_clip_array: s = x * 2^31 in float32; s >= 2^31 - 1 -> 0x7FFFFF, s <= -2^31 -> 0x800000,
+//    else the top three bytes of lrintf(s), i.e. lrintf(x * 2^31) >> 8 (a floor, not a rounding, of x * 2^23).
+//    Four samples (12 bytes) per thread.
 #include "ac_common.h"
 
 __global__ __launch_bounds__(256) void k_resample_poly(const float* __restrict__ x, int64_t n, int up, int down,
@@ -37,8 +39,11 @@ extern "C" int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, 
 }
 
 __device__ inline int pcm24(float v) {
-    const float s = rintf(v * 8388607.0f);               // lrintf under the default rounding mode: half to even
-    return s > 8388607.0f ? 8388607 : (s < -8388608.0f ? -8388608 : (int)s);
+    const float s = v * 2147483648.0f;                   // libsndfile: normfact = 8.0 * 0x10000000, product in float32
+    if (s >= 2147483647.0f) return 8388607;              // (float)0x7FFFFFFF == 2^31: every s >= 1.0 * 0x7FFFFFFF
+    if (s <= -2147483648.0f) return -8388608;
+    if (!(s == s)) return 0;                             // NaN: lrintf is undefined there; silence
+    return ((int)rintf(s)) >> 8;                         // lrintf (half to even), then the three high bytes
 }
 
 __global__ __launch_bounds__(256) void k_pack_pcm24(const float* __restrict__ x, int64_t n, unsigned char* __restrict__ out) {

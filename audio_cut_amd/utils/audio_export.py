@@ -2,9 +2,9 @@
 `build_export_options`, `export_audio`) and `core/utils/segment_exporter.py` (`ExportResult`, `SegmentExporter`) for the
 formats this build writes: WAV PCM_24 (the reference default, `audio_export.py:109-111`) and PCM_16.  SURVEY.md §8(f) row 4.
 
-The float -> integer conversion runs on the GPU (`ac_pack_pcm24`: rint(x * 8388607), clipped — libsndfile's normalised
-conversion, which soundfile.write applies; libsndfile wraps instead of clipping, the only deliberate difference) on the
-whole resident track once; segment files are byte slices of that buffer behind a 44-byte RIFF header.  MP3 needs
+The float -> integer conversion runs on the GPU (`ac_pack_pcm24`) on the whole resident track once and is libsndfile's
+clipping conversion - python-soundfile sets SFC_SET_CLIPPING on every file, so `soundfile.write` goes through pcm.c
+`f2let_clip_array`: `lrintf(x * 2^31) >> 8`, saturating at 0x7FFFFF / 0x800000 (`>> 16` for PCM_16); segment files are byte slices of that buffer behind a 44-byte RIFF header.  MP3 needs
 pydub + FFmpeg in the reference (`:114-135`) and is refused here.
 """
 from __future__ import annotations
@@ -46,12 +46,22 @@ def wav_header(n_frames: int, sample_rate: int, channels: int, bytes_per_sample:
             sample_rate * channels * bytes_per_sample, channels * bytes_per_sample, 8 * bytes_per_sample) + b"data" + struct.pack("<I", data))
 
 
+def _sndfile_clip_int32(x: np.ndarray) -> np.ndarray:
+    """libsndfile pcm.c f2le{s,t}_clip_array (python-soundfile enables SFC_SET_CLIPPING on every file): the sample times 2^31
+    in float32, saturated at 0x7FFFFFFF / -2^31, then lrintf (half to even).  The PCM word is its top 2 or 3 bytes."""
+    s = np.asarray(x, dtype=np.float32) * np.float32(2147483648.0)
+    v = np.rint(np.nan_to_num(s.astype(np.float64), nan=0.0, posinf=3e9, neginf=-3e9))
+    v = np.where(s >= np.float32(2147483647.0), 2147483647.0, np.where(s <= np.float32(-2147483648.0), -2147483648.0, v))
+    return v.astype(np.int64)
+
+
 def pcm_bytes_host(audio: np.ndarray, subtype: str) -> Tuple[np.ndarray, int]:
-    """Host conversion for arrays that never were on the device (tests, tiny inputs): same arithmetic as the kernel."""
+    """Host conversion for arrays that never were on the device (tests, tiny inputs): same arithmetic as the kernel, which is
+    libsndfile's clipping float -> PCM conversion: `lrintf(x * 2^31) >> 16` (PCM_16) / `>> 8` (PCM_24)."""
     x = np.asarray(audio, dtype=np.float32).reshape(-1)
     if subtype == "PCM_16":
-        return np.clip(np.rint(x * np.float32(32767.0)), -32768, 32767).astype("<i2").view(np.uint8), 2
-    v = np.clip(np.rint(x * np.float32(8388607.0)), -8388608, 8388607).astype(np.int32)
+        return (_sndfile_clip_int32(x) >> 16).astype("<i2").view(np.uint8), 2
+    v = (_sndfile_clip_int32(x) >> 8).astype(np.int32)
     out = np.empty((x.size, 3), dtype=np.uint8)
     out[:, 0] = v & 0xFF; out[:, 1] = (v >> 8) & 0xFF; out[:, 2] = (v >> 16) & 0xFF
     return out.reshape(-1), 3

@@ -10,8 +10,16 @@ quiet-guard cut refinement.  The track is resident in HBM when the timed region 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank runs K tracks (weak scaling; tracks are independent, no data-path
-collective), batch completion = RCCL barrier + all_gather_object of per-track summaries.
+Every step is a DIFFERENT track.  N = 1: seed 2 (the C2 track) first, then the C3 seeds 100, 101, ...  N > 1: one
+process per GPU; the N * K tracks of the job are the C3 seeds 100 .. 100 + N * K - 1 (N = 8, K = 4 is
+BASELINE configs[2] itself: 32 x 4-min tracks), dealt to the ranks by `audio_cut_amd.batch.assign_tracks` (weak
+scaling; tracks are independent, no data-path collective), batch completion = RCCL barrier + all_gather_object of
+per-track summaries.  Every track's boundary SHA-1 is compared with the committed single-GPU result of the same seed
+(tests/golden/c3_n1_sha1.json, written by `bench.py --config c3 --write-golden PATH`): "per-track boundaries identical to
+the single-GPU run" is checked inside the bench (`parity_vs_single_gpu`).  `--gpus N` without a launcher starts the
+N ranks itself (child processes, before anything touches the GPU).
+  --config c3   32 tracks (seeds 100-131) over the ranks present, K = 32 / N per rank
+  --config c5   BASELINE configs[4]: one 30-min track per step (240 chunks, 480 U-Net items)
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -34,9 +42,11 @@ METRIC = "audio-seconds processed/sec (separate+detect) per GPU; cut-point index
 F32_MATRIX_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_32x32x2_f32
 
 
-def cpu_baseline(sample_s: float, weights, spec) -> dict:
+def cpu_baseline(sample_s: float, weights, spec, single_thread_sample_s: float = 10.0) -> dict:
     """The oracle (CPU restatement of the reference path: torch-CPU STFT/U-Net/iSTFT + numpy detection and
-    guard) timed on this host's cores on a bounded sample of the same workload."""
+    guard) timed on this host's cores on a bounded sample of the same workload: once on the GPU's share of the host cores
+    (`value`) and once single-threaded (the reference's published detection figure is "single core"),
+    the latter on one 10 s chunk so the default run stays within minutes."""
     from audio_cut_amd.testing import signals
     from oracle import e2e as OE, refine as OR
     OR.LEGACY_PROMOTION = True
@@ -46,15 +56,33 @@ def cpu_baseline(sample_s: float, weights, spec) -> dict:
     except AttributeError:
         avail = os.cpu_count() or 1
     threads = int(os.environ.get("AC_CPU_BASELINE_THREADS", min(16, avail)))
-    torch.set_num_threads(threads)
-    mix = signals.c2_song(sample_s, seed=2)
-    t0 = time.perf_counter()
-    res = OE.run_track(mix, 44100, weights)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_s / dt, 4), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample_s:g} s of the C2 track generator (seed 2), full oracle path, one pass",
-            "seconds": round(dt, 2), "phases_s": {k: round(v, 3) for k, v in res.timings.items()},
-            "n_boundaries": len(res.sample_boundaries)}
+    saved = torch.get_num_threads()
+
+    def leg(seconds: float, n_threads: int) -> dict:
+        torch.set_num_threads(n_threads)
+        mix = signals.c2_song(seconds, seed=2)
+        t0 = time.perf_counter()
+        res = OE.run_track(mix, 44100, weights)
+        dt = time.perf_counter() - t0
+        return {"value": round(seconds / dt, 4), "cores": n_threads, "sample_audio_s": seconds, "seconds": round(dt, 2),
+                "phases_s": {k: round(v, 3) for k, v in res.timings.items()}, "n_boundaries": len(res.sample_boundaries)}
+
+    try:
+        multi = leg(sample_s, threads)
+        single = leg(single_thread_sample_s, 1) if single_thread_sample_s > 0 else None
+    finally:
+        torch.set_num_threads(saved)
+    out = {"value": multi["value"], "unit": "audio-s/s", "cores": threads, "kind": "port",
+           "sample": f"first {sample_s:g} s of the 240 s C2 track (generator seed 2) = {sample_s / 240.0:.1%} of BASELINE configs[1]: "
+                     f"{int(np.ceil(max(sample_s - 2.5, 0.0) / 7.5 + 1e-9)) if sample_s > 10 else 1} chunks through the full oracle path "
+                     "(torch-CPU STFT / U-Net / iSTFT, numpy features, detection, guard), one pass; the path is linear in "
+                     "track length (per-chunk U-Net dominates)",
+           "seconds": multi["seconds"], "phases_s": multi["phases_s"], "n_boundaries": multi["n_boundaries"]}
+    if single is not None:
+        out["single_thread"] = {"value": single["value"], "unit": "audio-s/s", "cores": 1,
+                                "sample": f"first {single_thread_sample_s:g} s of the same track (one chunk), torch / OpenMP pinned to 1 thread",
+                                "seconds": single["seconds"], "phases_s": single["phases_s"]}
+    return out
 
 
 class SocketSampler:
@@ -159,10 +187,18 @@ def roofline_conv(probe, conv_ms: float, conv_flops: float, elapsed: float) -> d
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
 
 
-def framewise_rooflines(hip, mix_dev, reps: int = 5) -> list:
+def framewise_rooflines(hip, mix_dev, reps: int = 8) -> list:
     """the framewise / scan kernels are HBM-bound streaming passes; report achieved GB/s per kernel on the
-    C2 track (algorithmic bytes per launch / HIP-event time on the launch stream), outside the timed region."""
+    C2 track (algorithmic bytes per launch / HIP-event time on the launch stream), outside the timed region.  Each launch
+    reads a DIFFERENT copy of the track: 8 x 42 MB of float32 (and 8 x 85 MB of float64 for the scan) exceed the 256 MB
+    Infinity Cache, so these are HBM rates, not cache rates."""
     n = int(mix_dev.numel())
+    copies = [mix_dev] + [mix_dev.clone() for _ in range(7)]
+    turn = [0]
+
+    def nxt():
+        turn[0] = (turn[0] + 1) % len(copies)
+        return copies[turn[0]]
 
     def timed(fn) -> float:
         fn()
@@ -182,17 +218,39 @@ def framewise_rooflines(hip, mix_dev, reps: int = 5) -> list:
 
     for frame, hop in ((4410, 2205), (2048, 441), (2205, 882), (1102, 441)):
         nf = 1 + n // hop
-        add(f"ac_frame_rms({frame},{hop})", lambda f=frame, h=hop: hip.frame_rms(mix_dev, f, h), 4 * n + 4 * nf)
-    add("ac_stft2048_features(hop 441, flatness)", lambda: hip.stft2048_features(mix_dev, 441, want_flat=True, want_mel=False),
+        add(f"ac_frame_rms({frame},{hop})", lambda f=frame, h=hop: hip.frame_rms(nxt(), f, h), 4 * n + 4 * nf)
+    add("ac_stft2048_features(hop 441, flatness)", lambda: hip.stft2048_features(nxt(), 441, want_flat=True, want_mel=False),
         4 * n + 4 * (1 + n // 441))
-    add("ac_stft2048_features(hop 512, mel-128)", lambda: hip.stft2048_features(mix_dev, 512, want_flat=False, want_mel=True),
+    add("ac_stft2048_features(hop 512, mel-128)", lambda: hip.stft2048_features(nxt(), 512, want_flat=False, want_mel=True),
         4 * n + 512 * (1 + n // 512))
     _, mel = hip.stft2048_features(mix_dev, 512, want_flat=False, want_mel=True)
     add("ac_onset_strength(mean)", lambda: hip.onset_strength(mel, 512, "mean"), 2 * 512 * mel.shape[0] + 4 * mel.shape[0])
-    add("ac_moving_meansq_db_f64(W 3528)", lambda: hip.moving_meansq_db(mix_dev, 3528), 12 * n)
-    db = hip.moving_meansq_db(mix_dev, 3528)
-    add("ac_next_leq_scan", lambda: hip.next_leq_scan(db, -40.0), 16 * n)
+    add("ac_moving_meansq_db_f64(W 3528)", lambda: hip.moving_meansq_db(nxt(), 3528), 12 * n)
+    dbs = [hip.moving_meansq_db(c, 3528) for c in copies]
+    k = [0]
+
+    def scan():
+        k[0] = (k[0] + 1) % len(dbs)
+        return hip.next_leq_scan(dbs[k[0]], -40.0)
+    add("ac_next_leq_scan", scan, 16 * n)
     return rows
+
+
+C3_SEED0 = 100                         # C3 = 32 x C2 with seeds 100-131
+C3_GOLDEN = ROOT / "tests" / "golden" / "c3_n1_sha1.json"
+
+
+def _launch_ranks(n: int, argv: list) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of a torch.distributed.run child
+    (never an exec of this process; nothing here has touched the GPU yet) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    return subprocess.run(cmd).returncode
 
 
 def main() -> None:
@@ -200,16 +258,26 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--track-seconds", type=float, default=240.0)
+    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2",
+                    help="c2: 4-min tracks, K per rank (default; N > 1 deals the C3 seeds); c3: exactly the 32 C3 tracks over the ranks; "
+                         "c5: 30-min tracks")
+    ap.add_argument("--track-seconds", type=float, default=None, help="default 240 (c2 / c3) or 1800 (c5)")
     ap.add_argument("--items-per-forward", type=int, default=32)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="tracks in flight per GPU (audio_cut_amd.batch.TrackPipeline): 1 = strictly one after the other")
+    ap.add_argument("--write-golden", default=None, metavar="PATH",
+                    help="(c3, N = 1) write the per-track SHA-1 table of this run to PATH (committed as tests/golden/c3_n1_sha1.json)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(_launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or run `python bench.py --gpus {args.gpus}` and let it start the ranks")
     import torch.distributed as dist
     # Rehearsal switch for a ONE-GPU box only (never set by the driver): AC_BENCH_REHEARSAL=1 runs all ranks on cuda:0 with
     # the gloo backend, so the N > 1 control flow (barriers, MAX over ranks, summary gather) can be exercised without N GPUs.
@@ -242,20 +310,41 @@ def main() -> None:
     hip = _native.Context(device)
     backend = MDX23HipBackend(weights=weights, ctx=hip, max_items_per_forward=args.items_per_forward)
     backend.load_model()
-    depth = max(1, min(int(args.pipeline_depth), args.steps))
+
+    # ---- the job: which tracks, which of them are mine ------------------------------------------------------------------
+    track_s = float(args.track_seconds if args.track_seconds is not None else (1800.0 if args.config == "c5" else 240.0))
+    if args.config == "c3":
+        if 32 % world:
+            raise SystemExit("--config c3 needs a rank count that divides 32")
+        steps = 32 // world
+        seeds = [C3_SEED0 + i for i in range(32)]
+    elif args.config == "c5":
+        steps = args.steps
+        seeds = [5 + i for i in range(world * steps)]
+    else:
+        steps = args.steps
+        seeds = ([2] + [C3_SEED0 + i for i in range(steps - 1)]) if world == 1 else [C3_SEED0 + i for i in range(world * steps)]
+    mine = batch.assign_tracks([track_s] * len(seeds), world)[rank]            # longest-processing-time-first (equal lengths: round robin)
+    assert len(mine) == steps
+    make = (lambda sd: signals.c5_long_form(track_s, seed=sd)) if args.config == "c5" else (lambda sd: signals.c2_song(track_s, seed=sd))
+    depth = max(1, min(int(args.pipeline_depth), steps))
     splitters = [SeamlessSplitter(sr, separator=EnhancedVocalSeparator(sr, backend=backend)) for _ in range(depth)]
-    splitter = splitters[0]
     pipeline = batch.TrackPipeline(splitters, device)
+    gate = pipeline.separation_gate if depth > 1 else None
 
-    # every rank gets its own seeded track (C3-style seeds 100 + rank); rank 0 of a 1-GPU run uses the C2 seed
-    seed = 2 if world == 1 else 100 + rank
-    mix = signals.c2_song(args.track_seconds, seed=seed)
-    mix_dev = hip.to_device(mix)
-    torch.cuda.synchronize()
+    def job_for(mix, mix_dev):
+        return lambda sp: sp.split_track(mix, audio_dev=mix_dev, separation_gate=gate)
 
-    job = lambda sp: sp.split_track(mix, audio_dev=mix_dev, separation_gate=pipeline.separation_gate if depth > 1 else None)
-    if args.warmup > 0:
-        pipeline.run([job] * max(args.warmup, depth))            # every worker (its stream, its allocator pools) warms up
+    # every timed track is generated and made resident in HBM before the clock starts (BASELINE contract); warm-up tracks are
+    # tracks of their own (seeds 50, 51, ...) so nothing of a timed track has been seen before
+    tracks = [make(seeds[i]) for i in mine]
+    tracks_dev = [hip.to_device(m) for m in tracks]
+    n_warm = max(args.warmup, depth) if args.warmup > 0 else 0
+    if n_warm:
+        warm = [make(50 + (k % 2)) for k in range(min(n_warm, 2))]
+        warm_dev = [hip.to_device(m) for m in warm]
+        pipeline.run([job_for(warm[k % len(warm)], warm_dev[k % len(warm)]) for k in range(n_warm)])   # every worker (stream, allocator pools) warms up
+        del warm, warm_dev
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -268,20 +357,21 @@ def main() -> None:
     summaries = []
     sampler = SocketSampler(dev_index).start() if rank == 0 else None
     t0 = time.perf_counter()
-    step_results = pipeline.run([job] * args.steps)              # exactly K steps (tracks), `depth` of them in flight
+    step_results = pipeline.run([job_for(m, d) for m, d in zip(tracks, tracks_dev)])      # exactly K steps (tracks), `depth` of them in flight
     torch.cuda.synchronize()
     t_done = time.perf_counter()
     socket_state = sampler.stop() if sampler else {}
     for step, res in enumerate(step_results):
-        ts = t0
         st = res["gpu_meta"].get("gpu_pipeline_stage_ms", {})
         unet_ms += st.get("unet_ms", 0.0); stft_ms += st.get("stft_ms", 0.0); istft_ms += st.get("istft_ms", 0.0)
         items += int(st.get("n_items", 0))
         for k in phases:
             phases[k] += res["timings"].get(k, 0.0)
         policy_s += float(res.get("timings_policy_s", 0.0))
-        summaries.append(batch.summarize(rank * args.steps + step, res["sample_boundaries"], args.track_seconds,
-                                         {"step_s": (t_done - ts) / args.steps}))
+        sm = batch.summarize(mine[step], res["sample_boundaries"], track_s, {"step_s": (t_done - t0) / steps})
+        sm["seed"] = seeds[mine[step]]; sm["rank"] = rank
+        sm["cuts_sha1"] = batch.summarize(0, res.get("cuts_samples", []), 0.0)["boundaries_sha1"]
+        summaries.append(sm)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -296,44 +386,74 @@ def main() -> None:
     conv_flops = sum(f for _, _, f in probe)
 
     if rank == 0:
-        total_audio = args.track_seconds * args.steps * world
+        res = step_results[-1]
+        total_audio = track_s * steps * world
         flops = spec.flops_per_item() * items
         achieved = flops / (unet_ms / 1e3) / 1e12 if unet_ms > 0 else 0.0
+        # "per-track boundaries identical to the single-GPU run" (SURVEY.md 8d C3): every track against the committed N = 1 result
+        golden = {}
+        if C3_GOLDEN.exists() and args.config != "c5" and track_s == 240.0:
+            golden = json.loads(C3_GOLDEN.read_text()).get("tracks", {})
+        checked = [(d, golden[str(d["seed"])]) for d in all_summaries if str(d["seed"]) in golden]
+        bad = [d["seed"] for d, g in checked if d["boundaries_sha1"] != g["boundaries_sha1"] or d["cuts_sha1"] != g["cuts_sha1"]]
+        parity = {"reference": "tests/golden/c3_n1_sha1.json (bench.py --config c3 --write-golden on one GPU)" if golden else None,
+                  "tracks_checked": len(checked), "tracks_identical": len(checked) - len(bad), "mismatched_seeds": bad,
+                  "unchecked_seeds": [d["seed"] for d in all_summaries if str(d["seed"]) not in golden]}
+        if args.write_golden and args.config == "c3" and world == 1:
+            Path(args.write_golden).write_text(json.dumps({"what": "per-track SHA-1 of the guard boundaries and of the manifest cuts of the 32 C3 tracks "
+                                                     "(c2_song 240 s, seeds 100-131, synth weights seed 0), one MI355X, bench.py --config c3",
+                                             "tracks": {str(d["seed"]): {"boundaries_sha1": d["boundaries_sha1"], "cuts_sha1": d["cuts_sha1"],
+                                                                         "n_boundaries": d["n_boundaries"]} for d in all_summaries}}, indent=1) + "\n")
+        workloads = {
+            "c2": "BASELINE configs[1]: 4-min 44.1 kHz synthetic song (stereo generator, mono down-mix), chunked MDX23 separation "
+                  "(full-size TFC-TDF, seeded synthetic weights) + TrackFeatureCache + chunked VAD + PureVocalPauseDetector + "
+                  "quiet-guard + boundary policy; one track per step, every step a different seed, resident in HBM"
+                  + ("" if world == 1 else f"; N > 1: the C3 seeds 100..{C3_SEED0 + world * steps - 1} dealt by assign_tracks"),
+            "c3": "BASELINE configs[2]: the 32 x 4-min C3 tracks (seeds 100-131) dealt over the ranks by assign_tracks, same path as configs[1]",
+            "c5": "BASELINE configs[4] after the loader: 30-min 44.1 kHz long-form track (C2 generator looped with per-section seeds), "
+                  "240 chunks / 480 U-Net items per track, same path as configs[1]",
+        }
         out = {
             "metric": METRIC, "value": round(total_audio / elapsed, 3), "unit": "audio-s/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: 4-min 44.1 kHz synthetic song (stereo generator, mono down-mix), chunked MDX23 "
-                            "separation (full-size TFC-TDF, seeded synthetic weights) + TrackFeatureCache + chunked VAD + "
-                            "PureVocalPauseDetector + quiet-guard; one track per step, resident in HBM",
-                "track_seconds": args.track_seconds, "chunks_per_track": len(res["gpu_meta"].get("gpu_pipeline_config", {})) and
-                res["gpu_meta"].get("gpu_pipeline_chunks"), "unet_items_per_track": items // max(1, args.steps),
-                "items_per_forward": args.items_per_forward, "tracks_per_gpu": args.steps, "sharding": "track-per-rank",
-                "pipeline_depth": depth,
+                "workload": workloads[args.config],
+                "track_seconds": track_s, "chunks_per_track": res["gpu_meta"].get("gpu_pipeline_chunks"),
+                "unet_items_per_track": items // max(1, steps),
+                "items_per_forward": args.items_per_forward, "tracks_per_gpu": steps, "sharding": "track-per-rank (assign_tracks, LPT)",
+                "track_seeds": [d["seed"] for d in all_summaries], "pipeline_depth": depth,
                 "real_time_factor": round(total_audio / elapsed / world, 2),
             },
             "roofline": roofline_conv(probe, conv_ms, conv_flops, elapsed),
             "unet_forward": {
-                "what": "whole TFC-TDF forward (f16x3 MFMA convs + TDF GEMMs + fused HIP epilogues + GEMM-form 2x2 "
-                        f"resampling), {args.items_per_forward} items per forward; algorithmic f32 FLOPs",
+                "what": "whole TFC-TDF forward (one hand-written MFMA kernel per layer: f16x3 convs / TDF GEMMs / 2x2 resampling, exact-f32 "
+                        f"narrow TDF pairs), {args.items_per_forward} items per forward; algorithmic f32 FLOPs",
                 "achieved": round(achieved, 2), "unit": "TFLOP/s", "f32_matrix_peak": F32_MATRIX_PEAK_TFLOPS, "flops_per_item": spec.flops_per_item(), "items": items,
                 "ms_total": round(unet_ms, 2), "share_of_step": round(unet_ms / 1e3 / max(1e-9, elapsed), 3),
             },
             "phases_note": "per-track phase times; with pipeline_depth > 1 the host-bound tail of one track overlaps the next track's U-Net, "
                            "so they add up to more than ms_per_step",
-            "phases_ms_per_step": {"separate": round(phases["separate_s"] / args.steps * 1e3, 2),
-                                   "detect": round(phases["detect_s"] / args.steps * 1e3, 2),
-                                   "finalize": round(phases["finalize_s"] / args.steps * 1e3, 2),
-                                   "boundary_policy": round(policy_s / args.steps * 1e3, 2),
-                                   "mdx_stft": round(stft_ms / args.steps, 2), "unet": round(unet_ms / args.steps, 2),
-                                   "mdx_istft": round(istft_ms / args.steps, 2)},
+            "phases_ms_per_step": {"separate": round(phases["separate_s"] / steps * 1e3, 2),
+                                   "detect": round(phases["detect_s"] / steps * 1e3, 2),
+                                   "finalize": round(phases["finalize_s"] / steps * 1e3, 2),
+                                   "boundary_policy": round(policy_s / steps * 1e3, 2),
+                                   "mdx_stft": round(stft_ms / steps, 2), "unet": round(unet_ms / steps, 2),
+                                   "mdx_istft": round(istft_ms / steps, 2)},
             "n_boundaries": all_summaries[0]["n_boundaries"], "boundaries_sha1": all_summaries[0]["boundaries_sha1"],
-            "n_manifest_cuts": len(res.get("cuts_samples", [])), "segment_layout_applied": bool(res.get("segment_layout_applied", False)),
-            "tracks_completed": len(all_summaries),
+            "n_manifest_cuts": len(step_results[0].get("cuts_samples", [])), "segment_layout_applied": bool(step_results[0].get("segment_layout_applied", False)),
+            "tracks_completed": len(all_summaries), "parity_vs_single_gpu": parity,
         }
         if world == 1:
-            out["framewise_rooflines"] = framewise_rooflines(hip, mix_dev)
+            # single-stream latency next to the pipelined throughput: one more track, strictly alone on the GPU (outside the timed region)
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            lat = splitters[0].split_track(tracks[0], audio_dev=tracks_dev[0])
+            torch.cuda.synchronize()
+            out["single_stream_latency_ms"] = round((time.perf_counter() - tl) * 1e3, 2)
+            out["single_stream_latency_note"] = "one track alone on the GPU (pipeline depth 1, host tail not overlapped); same result: " + \
+                str(lat["sample_boundaries"] == step_results[0]["sample_boundaries"])
+            out["framewise_rooflines"] = framewise_rooflines(hip, tracks_dev[0])
         if world == 1 and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds, weights, spec)
         out["socket_under_load"] = socket_state

@@ -283,8 +283,9 @@ int ac_segment_sumsq_peak(ac_ctx* ctx, const float* x, int64_t n, const int64_t*
  * n_pre_pad leading zeros scipy adds; out[m] = sum_q h[(m + n_pre_remove) * down - q * up] x[q], float64 accumulation. */
 int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* h, int64_t hlen, int64_t n_pre_remove,
                      float* out, int64_t n_out, void* stream);
-/* float32 -> little-endian PCM_24 (rint(x * 8388607), clipped): soundfile.write(subtype="PCM_24") behind
- * vocal_smart_splitter/utils/audio_export.py:109-111.  out [3 * n] bytes. */
+/* float32 -> little-endian PCM_24 as soundfile.write(subtype="PCM_24") writes it (vocal_smart_splitter/utils/audio_export.py:109-111):
+ * libsndfile's clipping conversion (python-soundfile sets SFC_SET_CLIPPING): lrintf(x * 2^31) >> 8, saturating at
+ * 0x7FFFFF / 0x800000 (pcm.c f2let_clip_array).  out [3 * n] bytes. */
 int ac_pack_pcm24(ac_ctx* ctx, const float* x, int64_t n, unsigned char* out, void* stream);
 
 /* ac_conv3x3_f16x3 with the graph's first 1x1 convolution (spec [B][C0][H][W], C0 <= 4, w1 [C_in][C0], b1 [C_in], + ReLU;

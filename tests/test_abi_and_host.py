@@ -201,3 +201,29 @@ def test_track_assignment_lpt():
     assert batch.assign_tracks([240.0] * 32, 8) == [[r + 8 * k for k in range(4)] for r in range(8)]
     parts = batch.assign_tracks([1800.0, 240.0, 240.0, 60.0, 600.0], 2)
     assert sorted(i for p in parts for i in p) == [0, 1, 2, 3, 4] and parts[0] == [0]
+
+
+def test_runtime_override_of_a_section_is_seen_by_child_lookups():
+    """Reference semantics (`config_manager.py:497-509`: `set_runtime_config` writes the value into the tree): a dict-valued
+    override of a section replaces that subtree, so every dotted child lookup sees it (and falls back to the call-site default
+    for keys the override leaves out); a child written afterwards lands inside it; the last write wins."""
+    from audio_cut_amd import config as C
+    saved = C.snapshot()
+    try:
+        C.reset_runtime_config()
+        assert C.get_config("segment_layout.enable") is True and C.get_config("segment_layout.soft_min_s") == 5.0
+        C.set_runtime_config({"segment_layout": {"enable": False, "soft_min_s": 7.0}})
+        assert C.get_config("segment_layout.enable") is False and C.get_config("segment_layout.soft_min_s") == 7.0
+        assert C.get_config("segment_layout.soft_max_s", 12.5) == 12.5
+        assert C.get_config("segment_layout") == {"enable": False, "soft_min_s": 7.0}
+        C.set_runtime_config({"segment_layout.soft_max_s": 9.0})
+        assert C.get_config("segment_layout") == {"enable": False, "soft_min_s": 7.0, "soft_max_s": 9.0}
+        C.set_runtime_config({"segment_layout": {"enable": True}})            # a later section write replaces the earlier child too
+        assert C.get_config("segment_layout.soft_max_s", None) is None and C.get_config("segment_layout.enable") is True
+        C.reset_runtime_config()
+        C.set_runtime_config({"quality_control.enforce_quiet_cut": {"enable": False}})
+        assert C.get_config("quality_control.enforce_quiet_cut.enable") is False
+        assert C.get_config("quality_control.min_split_gap") == 1.2           # siblings of the overridden subtree keep their defaults
+        assert C.get_config("quality_control")["enforce_quiet_cut"] == {"enable": False}
+    finally:
+        C.restore(saved)

@@ -13,13 +13,20 @@ SR = 44100
 
 
 def test_pcm24_arithmetic_and_wav_round_trip(tmp_path):
-    x = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 1.5, -1.5, 1e-7, 0.25 + 1 / 8388607 / 2], dtype=np.float32)
+    # known answers hand-derived from libsndfile pcm.c f2let_clip_array (what soundfile.write runs: python-soundfile enables
+    # SFC_SET_CLIPPING): s = x * 2^31 (float32); s >= 0x7FFFFFFF -> 0x7FFFFF; s <= -2^31 -> 0x800000; else lrintf(s) >> 8
+    q = 2.0 ** -23
+    x = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 1.5, -1.5, 1e-7, 0.9 * q, -0.1 * q, 1.0 - 2.0 ** -24, 3.0 * q, -3.0 * q, 2.5 * q,
+                  -(1.0 - q)], dtype=np.float32)
     b, width = AE.pcm_bytes_host(x, "PCM_24")
     assert width == 3 and b.size == 3 * x.size
     v = b.reshape(-1, 3).astype(np.int32)
     ints = v[:, 0] | (v[:, 1] << 8) | (v[:, 2] << 16)
     ints = np.where(ints & 0x800000, ints - 0x1000000, ints)
-    assert ints.tolist()[:7] == [0, 8388607, -8388607, 4194304, -4194304, 8388607, -8388608]     # rint half-to-even, clipped
+    #        0   1.0      -1.0      0.5      -0.5      1.5      -1.5     1e-7 .9q -.1q  1-2^-24  3q  -3q 2.5q -(1-q)
+    assert ints.tolist() == [0, 8388607, -8388608, 4194304, -4194304, 8388607, -8388608, 0, 0, -1, 8388607, 3, -3, 2, -8388607]
+    b16, w16 = AE.pcm_bytes_host(np.array([0.0, 1.0, -1.0, 0.5, 0.9 * 2.0 ** -15, -0.1 * 2.0 ** -15, 1.5], np.float32), "PCM_16")
+    assert w16 == 2 and b16.view("<i2").tolist() == [0, 32767, -32768, 16384, 0, -1, 32767]      # lrintf(x * 2^31) >> 16
     p = AE.export_audio(x, SR, tmp_path / "seg_1.5", "wav")
     assert p.name == "seg_1.5.wav"                                           # a dotted base keeps its dot (`audio_export.py:83-86`)
     with wave.open(str(p), "rb") as w:

@@ -425,3 +425,113 @@ def test_track_pipeline_matches_sequential_processing(hip_ctx):
     assert [s["track"] for s in batch.gather_summaries(summaries)] == list(range(6))
     with pytest.raises(ValueError):                                           # a failing job surfaces, the pipeline does not hang
         pipe.run([lambda sp: sp.split_track(np.zeros(0, np.float32))])
+
+
+def _oracle_fixture_asserts(res, g, mix):
+    """What every full-size oracle fixture (tests/golden/make_c2_full.py) pins: guard boundaries, manifest cuts, labels, pause cut
+    points, VAD segments and beat grid exact; stems and RMS series within the north-star tolerance (1e-4)."""
+    assert res["sample_boundaries"] == g["sample_boundaries"].tolist()
+    assert res["cuts_samples"] == g["cuts"].tolist()
+    assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
+    assert [list(p) for p in res["segment_spans"]] == g["pieces"].tolist()
+    assert np.array_equal(np.asarray([p.cut_point for p in res["pauses"]]), g["pause_cut_points"])
+    assert np.array_equal(np.asarray([[s["start"], s["end"]] for s in res["vad_segments"]]), g["vad_segments"])
+    assert np.array_equal(np.asarray(res["feature_cache"].beat_times), g["beat_times"])
+    np.testing.assert_allclose(res["feature_cache"].rms_series, g["cache_rms"], rtol=SERIES_RTOL, atol=1e-7)
+    voc = res["vocal_track"]
+    peak = float(g["vocal_peak"])
+    head_err = float(np.max(np.abs(voc[: 4 * SR: 7] - g["vocal_head"]))) / peak
+    assert head_err < STEM_RTOL
+    nsec = len(mix) // SR
+    rms = np.sqrt(np.mean(voc[: nsec * SR].reshape(nsec, SR).astype(np.float64) ** 2, axis=1))
+    np.testing.assert_allclose(rms, g["vocal_rms_per_second"], rtol=1e-4, atol=1e-4 * peak)
+    return head_err
+
+
+def test_c5_long_form_end_to_end_against_oracle_fixture(hip_ctx, golden_dir):
+    """BASELINE configs[4] end to end AFTER the loader (the parity input is defined after resampling): a 30-min
+    track (C2 generator looped with per-section seeds, 240 chunks, 480 U-Net items with the real - synthetic-weight - U-Net)
+    through separation, feature cache, VAD, pause detection, quiet guard and the boundary policy, against the CPU oracle's
+    committed result (`make_c2_full.py 1800 5 c5_1800s_seed5_oracle c5_long_form 0`: 37 min of oracle time): all 201 guard
+    boundaries, 241 manifest cuts, labels, 240 pause cut points, VAD segments and 3599 beats exact; stems within 1e-4."""
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    g = np.load(golden_dir / "c5_1800s_seed5_oracle.npz")
+    mix = signals.c5_long_form(1800.0, seed=5)
+    assert len(mix) == 1800 * SR
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=0), ctx=hip_ctx, max_items_per_forward=32)
+    backend.load_model()
+    sp = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend))
+    res = sp.split_track(mix)
+    assert res["gpu_meta"]["gpu_pipeline_chunks"] == 240 and len(g["sample_boundaries"]) == 201
+    err = _oracle_fixture_asserts(res, g, mix)
+    print(f"C5: 201 boundaries / 241 cuts exact, vocal stem error {err:.2e} of peak")
+
+
+def test_c5_loader_leg_48k_stereo_at_full_length(hip_ctx):
+    """The load leg of BASELINE configs[4] at full size: 30 min of 48 kHz stereo -> channel mean -> ac_resample_poly 147/160 on
+    the device (the reference: librosa.load(sr=44100, mono=True), `audio_processor.py:45-49`; its soxr_hq filter cannot be pinned
+    offline, so this row's parity definition is scipy.signal.resample_poly - see DESIGN.md).  Properties at 86.4 M input samples:
+    exact output length, agreement with scipy on windows spread over the track (the FIR is local), exact homogeneity under a
+    power-of-two gain, and section energies preserved (the source has < 0.1 % of its energy above 20 kHz)."""
+    import scipy.signal
+    st = signals.c5_long_form(1800.0, seed=5, sr=48000, stereo=True)
+    assert st.shape == (2, 1800 * 48000)
+    mono = np.mean(st, axis=0).astype(np.float32)
+    del st
+    dev = hip_ctx.to_device(mono)
+    y = hip_ctx.resample_poly(dev, 147, 160)
+    n_out = -(-len(mono) * 147 // 160)
+    assert y.numel() == n_out == 1800 * SR
+    yh = y.cpu().numpy()
+    assert np.all(np.isfinite(yh))
+    rng = np.random.default_rng(3)
+    for c in [0, len(mono) - 480000] + [int(v) for v in rng.integers(10_000_000, len(mono) - 10_000_000, 6)]:
+        c -= c % 160                                     # window starts on a polyphase period: output index = c * 147 / 160 exactly
+        lo = max(0, c - 160 * 40); hi = min(len(mono), c + 480000 + 160 * 40)
+        ref = scipy.signal.resample_poly(mono[lo:hi], 147, 160)
+        o0 = c * 147 // 160; r0 = (c - lo) * 147 // 160
+        n_cmp = 400000 * 147 // 160
+        assert float(np.max(np.abs(yh[o0:o0 + n_cmp] - ref[r0:r0 + n_cmp]))) < 2e-6 * max(1.0, float(np.max(np.abs(ref)))), c
+        if hi == len(mono):                              # the track's tail: the same zero padding past the last sample
+            assert float(np.max(np.abs(yh[-2000:] - ref[-2000:]))) < 2e-6
+    y2 = hip_ctx.resample_poly(dev * 0.5, 147, 160).cpu().numpy()
+    assert np.array_equal(y2, yh * np.float32(0.5))      # homogeneity: float64 accumulation of exactly halved terms
+    sec_in = mono[: 30 * 60 * 48000].reshape(30, -1).astype(np.float64); sec_out = yh.reshape(30, -1).astype(np.float64)
+    e_in = np.mean(sec_in ** 2, axis=1); e_out = np.mean(sec_out ** 2, axis=1)
+    assert np.all(np.abs(e_out / e_in - 1.0) < 2e-3)
+
+
+def test_c3_batch_of_32_tracks_on_one_gpu(hip_ctx, golden_dir):
+    """BASELINE configs[2] on one GPU: the 32 C3 tracks (c2_song, seeds 100-131) through `batch.TrackPipeline` exactly as
+    `bench.py --config c3` runs them.  Every track's guard boundaries and manifest cuts hash to the committed single-GPU
+    result (tests/golden/c3_n1_sha1.json - the table `bench.py --gpus N` checks every rank's tracks against), the LPT deal
+    over 8 ranks is the C3 sharding (4 tracks each), and the first and last track are also checked against the CPU oracle
+    (tests/golden/c3_seed100_oracle.npz, c3_seed131_oracle.npz)."""
+    import json
+    from audio_cut_amd import batch
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    table = json.loads((golden_dir / "c3_n1_sha1.json").read_text())["tracks"]
+    seeds = list(range(100, 132))
+    assert sorted(int(k) for k in table) == seeds
+    assert batch.assign_tracks([240.0] * 32, 8) == [[r + 8 * k for k in range(4)] for r in range(8)]
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=0), ctx=hip_ctx, max_items_per_forward=32)
+    backend.load_model()
+    sps = [SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend)) for _ in range(2)]
+    pipe = batch.TrackPipeline(sps, hip_ctx.device)
+    oracle = {100: np.load(golden_dir / "c3_seed100_oracle.npz"), 131: np.load(golden_dir / "c3_seed131_oracle.npz")}
+    for lo in range(0, 32, 8):                       # eight tracks resident at a time
+        mixes = [signals.c2_song(240.0, seed=s) for s in seeds[lo:lo + 8]]
+        devs = [hip_ctx.to_device(m) for m in mixes]
+        out = pipe.run([(lambda sp, m=m, d=d: sp.split_track(m, audio_dev=d, separation_gate=pipe.separation_gate)) for m, d in zip(mixes, devs)])
+        for s, m, r in zip(seeds[lo:lo + 8], mixes, out):
+            sm = batch.summarize(s, r["sample_boundaries"], 240.0)
+            assert sm["boundaries_sha1"] == table[str(s)]["boundaries_sha1"], s
+            assert batch.summarize(0, r["cuts_samples"], 0.0)["boundaries_sha1"] == table[str(s)]["cuts_sha1"], s
+            if s in oracle:
+                _oracle_fixture_asserts(r, oracle[s], m)
