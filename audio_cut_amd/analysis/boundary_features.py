@@ -1,7 +1,8 @@
 """Normalised boundary features for VPBD scoring — mirrors the reference's
 `src/audio_cut/analysis/boundary_features.py:16-167`.  The lyrics timeline is always empty on the
-acoustic path (`vpbd_acoustic`; the ASR providers are out of scope), so the word /
-sentence / singing features evaluate over empty lists exactly as the reference's do."""
+acoustic path (`vpbd_acoustic`; the ASR providers are out of scope): the four lyrics-derived
+features (`asr_gap`, `sentence_end`, `inside_word_penalty`, `singing_penalty`) are therefore constants 0 here and their
+evaluators are not built; the fields stay because the scorer's weight table names them."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -16,13 +17,10 @@ def _clamp01(v: float) -> float:
 
 @dataclass
 class LyricsTimeline:
-    """The slice of `audio_cut.lyrics.models.LyricsTimeline` the acoustic path touches."""
+    """The slice of `audio_cut.lyrics.models.LyricsTimeline` the acoustic path touches: an empty timeline."""
 
     duration_s: float = 0.0
     source: str = "none"
-    words: List = field(default_factory=list)
-    sentences: List = field(default_factory=list)
-    vad_regions: List = field(default_factory=list)
     warnings: List[str] = field(default_factory=list)
 
     def to_dict(self) -> Dict:
@@ -63,9 +61,6 @@ class BoundaryFeatureExtractor:
     rms_series: Iterable[float] = field(default_factory=list)
     hop_s: float = 0.0
     high_confidence: float = 0.85
-    word_gap_norm_s: float = 1.5
-    sentence_tolerance_s: float = 0.25
-    word_edge_tolerance_ms: float = 60.0
     affinity_tolerance_s: float = 0.12
     vocal_risk_window_s: float = 0.08
 
@@ -78,44 +73,9 @@ class BoundaryFeatureExtractor:
 
     def extract(self, t: float, *, acoustic_pause: float = 0.0) -> BoundaryFeatures:
         return BoundaryFeatures(
-            acoustic_pause=acoustic_pause, asr_gap=self._asr_gap(t), sentence_end=self._sentence_end(t),
-            inside_word_penalty=self._inside_word(t), singing_penalty=self._singing(t),
+            acoustic_pause=acoustic_pause,            # asr_gap / sentence_end / inside_word / singing: no lyrics timeline on this path -> 0
             beat_affinity=self._affinity(t, self.beat_times), mdd_affinity=self._affinity(t, self.mdd_times),
             vocal_cut_risk=self._vocal_cut_risk(t), beat_conflict=self._beat_conflict(t))
-
-    # -- lyrics-derived terms (empty timeline on the acoustic path) -------------------------------------
-    def _inside_word(self, t: float) -> float:
-        for w in self.timeline.words:
-            if w.start_s < t < w.end_s:
-                base = 0.5 if w.confidence is None else (1.0 if w.confidence >= self.high_confidence else 0.3)
-                tol = max(0.0, self.word_edge_tolerance_ms / 1000.0)
-                if tol <= 0.0:
-                    return base
-                edge = min(t - w.start_s, w.end_s - t)
-                return base * _clamp01(edge / tol) if edge < tol else base
-        return 0.0
-
-    def _singing(self, t: float) -> float:
-        for r in self.timeline.vad_regions:
-            if r.kind == "singing" and r.start_s < t < r.end_s:
-                return 0.5 if r.confidence is None else (1.0 if r.confidence >= self.high_confidence else 0.3)
-        return 0.0
-
-    def _asr_gap(self, t: float) -> float:
-        for a, b in zip(self.timeline.words, self.timeline.words[1:]):
-            if a.end_s <= t <= b.start_s:
-                return _clamp01(max(0.0, b.start_s - a.end_s) / max(self.word_gap_norm_s, 1e-6))
-        return 0.0
-
-    def _sentence_end(self, t: float) -> float:
-        best = 0.0
-        for s in self.timeline.sentences:
-            d = abs(t - s.end_s)
-            if d > self.sentence_tolerance_s:
-                continue
-            conf = s.confidence if s.confidence is not None else 1.0
-            best = max(best, conf * (1.0 - d / max(self.sentence_tolerance_s, 1e-6)))
-        return _clamp01(best)
 
     # -- acoustic terms ---------------------------------------------------------------------------------
     def _vocal_cut_risk(self, t: float) -> float:

@@ -177,7 +177,7 @@ class VocalPhraseBoundaryDetector:
         hop_s = float(getattr(feature_cache, "hop_s", 0.0) or 0.0) if feature_cache is not None else 0.0
         extractor = BoundaryFeatureExtractor(
             timeline=timeline, beat_times=beat_times, mdd_times=self._mdd_valley_times(feature_cache), rms_series=rms_series,
-            hop_s=hop_s, word_edge_tolerance_ms=float(_section("phrase_boundary").get("word_edge_tolerance_ms", 60.0)))
+            hop_s=hop_s)
         scorer = PhraseBoundaryScorer.from_config(_section("phrase_boundary"))
         out: List[CutCandidate] = []
         for c in candidates:

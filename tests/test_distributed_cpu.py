@@ -35,3 +35,22 @@ def test_two_rank_track_sharding(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a = np.load(tmp_path / "rank0.npy"); b = np.load(tmp_path / "rank1.npy")
     assert np.array_equal(a, b) and len(a) == 5          # every rank ends with the same complete, ordered summary
+
+
+def test_c3_single_gpu_table_agrees_with_the_cpu_oracle(golden_dir=None):
+    """tests/golden/c3_n1_sha1.json (the per-track result of the 32 C3 tracks on one MI355X, what `bench.py --gpus N` checks
+    every rank's tracks against) hashes the SAME integers the CPU oracle produced for the two tracks it was run on
+    (c3_seed100_oracle.npz, c3_seed131_oracle.npz: 4 min of oracle time each): guard boundaries and manifest cuts."""
+    import hashlib
+    import json
+    from pathlib import Path
+    import numpy as np
+    gd = Path(__file__).resolve().parent / "golden"
+    table = json.loads((gd / "c3_n1_sha1.json").read_text())["tracks"]
+    assert sorted(int(k) for k in table) == list(range(100, 132))
+    for seed in (100, 131):
+        g = np.load(gd / f"c3_seed{seed}_oracle.npz")
+        assert int(g["seed"]) == seed and float(g["seconds"]) == 240.0
+        assert hashlib.sha1(g["sample_boundaries"].astype(np.int64).tobytes()).hexdigest() == table[str(seed)]["boundaries_sha1"]
+        assert hashlib.sha1(g["cuts"].astype(np.int64).tobytes()).hexdigest() == table[str(seed)]["cuts_sha1"]
+        assert len(g["sample_boundaries"]) == table[str(seed)]["n_boundaries"]

@@ -535,3 +535,34 @@ def test_c3_batch_of_32_tracks_on_one_gpu(hip_ctx, golden_dir):
             assert batch.summarize(0, r["cuts_samples"], 0.0)["boundaries_sha1"] == table[str(s)]["cuts_sha1"], s
             if s in oracle:
                 _oracle_fixture_asserts(r, oracle[s], m)
+
+
+def test_build_feature_cache_whole_track_variant(hip_ctx):
+    """`build_feature_cache` (`features_cache.py:355-398,483-509`, the fallback the orchestrator takes when the
+    separator hands back no cache, `seamless_splitter.py:332-343`) on the full 4-min C2 track against the oracle's whole-track
+    builder: float series within the series tolerance, every integer / decision-carrying field exact; and against the chunked
+    builder's cache of the same track, from which it may differ only where chunk edges truncate an STFT frame."""
+    from audio_cut_amd.analysis.features_cache import build_feature_cache
+    mix = signals.c2_song(240.0, seed=2)
+    dev = hip_ctx.to_device(mix)
+    cache = build_feature_cache(mix, None, SR, ctx=hip_ctx, mix_dev=dev)
+    ocache = OF.whole_track_cache(mix, SR)
+    assert cache.sr == SR and cache.hop_length == 2205 and abs(cache.duration_s - 240.0) < 1e-9
+    for name in ("rms_series", "spectral_flatness", "onset_envelope", "mdd_series"):
+        a, b = getattr(cache, name), getattr(ocache, name)
+        assert len(a) == len(b) == 4801, name
+        np.testing.assert_allclose(a, b, rtol=SERIES_RTOL, atol=2e-5, err_msg=name)
+    assert np.array_equal(cache.onset_frames, ocache.onset_frames)
+    assert np.array_equal(cache.beat_times, ocache.beat_times)
+    assert np.array_equal(cache.tempo_curve, ocache.tempo_curve)
+    assert float(cache.bpm_features.main_bpm) == float(ocache.bpm_features.main_bpm)
+    assert np.array_equal(cache.bpm_features.beat_positions, ocache.bpm_features.beat_positions)
+    np.testing.assert_allclose(cache.global_mdd, ocache.global_mdd, rtol=1e-5)
+    np.testing.assert_allclose(cache.rms_max, ocache.rms_max, rtol=SERIES_RTOL)
+    # accessors the consumers use (`features_cache.py:60-91`)
+    assert cache.frame_index(12.34) == ocache.frame_index(12.34) == int(np.clip(round(12.34 / 0.05), 0, 4800))
+    # a call without a context or device copy builds its own (no CPU path: it needs the GPU)
+    again = build_feature_cache(mix, None, SR)
+    assert np.array_equal(again.rms_series, cache.rms_series) and np.array_equal(again.beat_times, cache.beat_times)
+    with pytest.raises(ValueError):
+        build_feature_cache(np.zeros(0, np.float32), None, SR, ctx=hip_ctx)

@@ -189,34 +189,13 @@ def test_candidate_and_feature_containers_clamp():
     assert adapted[0].meta["rms_valley_db"] == -45.0 and "legacy_acoustic" in adapted[0].reasons
 
 
-def _word(text, a, b, confidence=None):
-    return NS(text=text, start_s=a, end_s=b, confidence=confidence)
-
-
-def _sung_timeline() -> LyricsTimeline:
-    return LyricsTimeline(
-        words=[_word("hello", 0.50, 0.90, 0.95), _word("world", 1.40, 1.80, 0.94), _word("again", 3.00, 3.50, 0.40)],
-        sentences=[_word("hello world!", 0.50, 1.80, 0.90)],
-        vad_regions=[NS(start_s=0.45, end_s=1.90, confidence=0.92, kind="singing"), NS(start_s=2.80, end_s=3.70, confidence=0.40, kind="singing")],
-        duration_s=5.0, source="fake")
-
-
-def test_feature_extractor_word_singing_and_gap_terms():
-    ex = BoundaryFeatureExtractor(timeline=_sung_timeline(), beat_times=[1.0, 2.0], mdd_times=[1.6])
-    inside, low_conf, gap = ex.extract(0.70), ex.extract(3.20), ex.extract(1.15)
-    assert inside.inside_word_penalty == 1.0 and inside.singing_penalty == 1.0
-    assert 0.0 < low_conf.inside_word_penalty < 1.0 and 0.0 < low_conf.singing_penalty < 1.0
-    assert gap.asr_gap > 0.0
-    f = BoundaryFeatureExtractor(timeline=_sung_timeline(), beat_times=[1.80], mdd_times=[1.78], affinity_tolerance_s=0.05).extract(1.80)
-    assert f.sentence_end > 0.0 and f.beat_affinity == 1.0 and f.mdd_affinity > 0.0
-
-
-def test_feature_extractor_tolerances_and_risk_terms():
-    line = LyricsTimeline(words=[_word("line", 1.0, 2.0, 0.95)], sentences=[_word("line.", 1.0, 2.0, 1.0)], duration_s=4.0, source="fake")
-    assert BoundaryFeatureExtractor(timeline=line).extract(1.85).sentence_end > 0.0
-    ex = BoundaryFeatureExtractor(timeline=line, word_edge_tolerance_ms=60.0)
-    centre, edge = ex.extract(1.50), ex.extract(1.98)
-    assert centre.inside_word_penalty == 1.0 and 0.0 < edge.inside_word_penalty < centre.inside_word_penalty
+def test_feature_extractor_affinity_and_risk_terms():
+    """The acoustic terms of the reference's feature-extractor tests (`tests/unit/test_boundary_features*.py`); the lyrics-derived
+    terms have no evaluator here (no ASR timeline on this path) and stay 0."""
+    f = BoundaryFeatureExtractor(timeline=LyricsTimeline(duration_s=5.0, source="none"), beat_times=[1.80], mdd_times=[1.78],
+                                 affinity_tolerance_s=0.05).extract(1.80)
+    assert f.beat_affinity == 1.0 and f.mdd_affinity > 0.0
+    assert f.asr_gap == f.sentence_end == f.inside_word_penalty == f.singing_penalty == 0.0
     rms = np.full(100, 0.1, dtype=np.float32); rms[39:43] = 1.0
     ex = BoundaryFeatureExtractor(timeline=LyricsTimeline(duration_s=5.0, source="none"), rms_series=rms, hop_s=0.05)
     assert ex.extract(0.25).vocal_cut_risk < 0.2 and ex.extract(2.0).vocal_cut_risk > 0.8
