@@ -91,6 +91,10 @@ SIGNATURES = {
     "ac_local_valley": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ac_resample_poly": (C.c_int, [_P, _P, _I64, _I, _I, _P, _I64, _I64, _P, _I64, _P]),
     "ac_pack_pcm24": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "ac_resample_poly_segments": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I64, _I64, _P, _I64, _P]),
+    "ac_silero_frontend": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ac_silero_lstm": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P]),
+    "ac_silero_out": (C.c_int, [_P, _P, _P, C.c_float, _I, _P, _P]),
     "ac_host_beat_dp": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P, _P]),
 }
 
@@ -220,10 +224,21 @@ class Context:
         return float(sr) / period.cpu().numpy(), cmnd
 
     # -- loader / exporter ---------------------------------------------------
+    @staticmethod
+    def _resample_filter(up: int, down: int):
+        """scipy.signal.resample_poly's default design: Kaiser(5.0) windowed sinc of half length 10 * max(up, down), scaled by
+        `up`, front-padded so that the output is aligned; returns (h float32, n_pre_remove)."""
+        import scipy.signal
+        half_len = 10 * max(up, down)
+        h = scipy.signal.firwin(2 * half_len + 1, 1.0 / max(up, down), window=("kaiser", 5.0)).astype(np.float32)
+        h *= up
+        n_pre_pad = down - half_len % down
+        n_pre_remove = (half_len + n_pre_pad) // down
+        return np.concatenate((np.zeros(n_pre_pad, dtype=np.float32), h)), n_pre_remove
+
     def resample_poly(self, x: torch.Tensor, up: int, down: int) -> torch.Tensor:
         """scipy.signal.resample_poly(x, up, down) on the device (default Kaiser(5.0) design, zero padding)."""
         import math
-        import scipy.signal
         self._chk_f32(x)
         g = math.gcd(int(up), int(down))
         up, down = int(up) // g, int(down) // g
@@ -232,16 +247,59 @@ class Context:
         n = x.numel()
         n_out = n * up
         n_out = n_out // down + bool(n_out % down)
-        half_len = 10 * max(up, down)
-        h = scipy.signal.firwin(2 * half_len + 1, 1.0 / max(up, down), window=("kaiser", 5.0)).astype(np.float32)
-        h *= up
-        n_pre_pad = down - half_len % down
-        n_pre_remove = (half_len + n_pre_pad) // down
-        h = np.concatenate((np.zeros(n_pre_pad, dtype=np.float32), h))
+        h, n_pre_remove = self._resample_filter(up, down)
         hd = self.to_device(h)
         out = torch.empty(n_out, dtype=torch.float32, device=self.device)
         _check(self.lib.ac_resample_poly(self._h, _ptr(x), n, up, down, _ptr(hd), h.size, n_pre_remove, _ptr(out), n_out, _stream()))
         return out
+
+    def resample_poly_segments(self, x: torch.Tensor, offsets: Sequence[int], lengths: Sequence[int], up: int, down: int, bucket: int = 0):
+        """`resample_poly` of every segment x[offsets[s] : offsets[s] + lengths[s]] on its own, one launch.  Returns (out, out_off,
+        out_len): segment s's result is out[out_off[s] : out_off[s] + out_len[s]], followed by zeros up to the next multiple of
+        `bucket` (0 = no padding)."""
+        import math
+        self._chk_f32(x)
+        g = math.gcd(int(up), int(down))
+        up, down = int(up) // g, int(down) // g
+        lengths = [int(v) for v in lengths]
+        out_len = [(n * up) // down + bool((n * up) % down) for n in lengths]
+        padded = [n + ((-n) % bucket if bucket > 0 else 0) for n in out_len]
+        out_off = np.concatenate(([0], np.cumsum(padded))).astype(np.int64)
+        total = int(out_off[-1])
+        out = torch.zeros(max(total, 1), dtype=torch.float32, device=self.device)
+        if total == 0:
+            return out[:0], out_off[:-1], out_len
+        if up == down == 1:
+            for o, n, oo in zip(offsets, lengths, out_off[:-1]):
+                out[int(oo): int(oo) + n] = x[int(o): int(o) + n]
+            return out, out_off[:-1], out_len
+        h, n_pre_remove = self._resample_filter(up, down)
+        hd = self.to_device(h)
+        d_io = self.to_device(np.asarray(offsets, dtype=np.int64)); d_il = self.to_device(np.asarray(lengths, dtype=np.int64))
+        d_oo = self.to_device(out_off[:-1].copy()); d_ol = self.to_device(np.asarray(out_len, dtype=np.int64))
+        _check(self.lib.ac_resample_poly_segments(self._h, _ptr(x), _ptr(d_io), _ptr(d_il), _ptr(d_oo), _ptr(d_ol), len(lengths), up, down,
+                                                  _ptr(hd), h.size, n_pre_remove, _ptr(out), total, _stream()))
+        return out, out_off[:-1], out_len
+
+    # -- Silero VAD network (detectors/silero_vad.py packs the weights) ------------------------------------
+    def silero_probs(self, x16: torch.Tensor, win_start: np.ndarray, seg_first: np.ndarray, seg_count: np.ndarray, packed: dict) -> torch.Tensor:
+        """Speech probability of every 512-sample window (include/audiocut_hip.h: ac_silero_frontend / _lstm / _out).
+        `win_start[w]` = index in x16 of the window's first new sample, `-(index) - 1` for the first window of a chunk;
+        chunk s owns windows seg_first[s] .. + seg_count[s] (LSTM state reset per chunk)."""
+        self._chk_f32(x16)
+        n_win = int(len(win_start))
+        d_ws = self.to_device(np.asarray(win_start, dtype=np.int64))
+        d_sf = self.to_device(np.asarray(seg_first, dtype=np.int32)); d_sc = self.to_device(np.asarray(seg_count, dtype=np.int32))
+        gates = torch.empty((n_win, 512), dtype=torch.float32, device=self.device)
+        hs = torch.empty((n_win, 128), dtype=torch.float32, device=self.device)
+        probs = torch.empty(n_win, dtype=torch.float32, device=self.device)
+        p = packed
+        _check(self.lib.ac_silero_frontend(self._h, _ptr(x16), _ptr(d_ws), n_win, _ptr(p["basis_t"]), _ptr(p["c1"]), _ptr(p["b1"]),
+                                           _ptr(p["c2"]), _ptr(p["b2"]), _ptr(p["c3"]), _ptr(p["b3"]), _ptr(p["c4"]), _ptr(p["b4"]),
+                                           _ptr(p["wih_t"]), _ptr(p["bias_sum"]), _ptr(gates), _stream()))
+        _check(self.lib.ac_silero_lstm(self._h, _ptr(gates), _ptr(d_sf), _ptr(d_sc), len(seg_first), _ptr(p["whh_t"]), _ptr(hs), _stream()))
+        _check(self.lib.ac_silero_out(self._h, _ptr(hs), _ptr(p["w_out"]), float(p["b_out"]), n_win, _ptr(probs), _stream()))
+        return probs
 
     def pack_pcm24(self, x: torch.Tensor) -> np.ndarray:
         """float32 device track -> host uint8 array of 3 * n little-endian PCM_24 bytes."""

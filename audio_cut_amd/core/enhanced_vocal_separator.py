@@ -236,11 +236,14 @@ class EnhancedVocalSeparator:
             stems_on_host.record()
 
         # 3. chunked VAD on the per-chunk vocals (enhanced_vocal_separator.py:331-333,412-417)
-        vad_fn = self._vad_inference_fn or EnergyGateVad(sr, hip)
+        if self._vad_inference_fn is None:        # Silero network when weights are configured, else the no-weights energy gate
+            from ..detectors.silero_vad import default_vad
+            self._vad_inference_fn = default_vad(sr, hip)
+        vad_fn = self._vad_inference_fn
         chunk_vad = SileroChunkVAD(sample_rate=sr, merge_gap_ms=float(get_config("advanced_vad.silero_merge_gap_ms", 120.0)),
                                    focus_pad_s=float(get_config("advanced_vad.focus_window_pad_s", 0.2)), inference_fn=vad_fn)
-        if isinstance(vad_fn, EnergyGateVad):     # every chunk's window RMS in one launch and one download
-            pre = vad_fn.batch_rms(sep.chunk_vocal, sep.chunk_offsets, [ce - cs for cs, ce, _, _ in sep.chunk_ranges])
+        if hasattr(vad_fn, "precompute"):         # every chunk's windows in one batch of launches and one download
+            pre = vad_fn.precompute(sep.chunk_vocal, sep.chunk_offsets, [ce - cs for cs, ce, _, _ in sep.chunk_ranges])
             for plan, chunk in zip(live_plans, pre):
                 chunk_vad.process_chunk(plan, chunk, sr)
         else:                                     # injected VadFn contract: host float32 chunks

@@ -2,13 +2,14 @@
 (`SileroChunkVAD(sample_rate, merge_gap_ms=120.0, focus_pad_s=0.2, inference_fn=None)`,
 `process_chunk / finalize / to_focus_windows / build_focus_windows`, `VadFn` contract `:24,95-102`).
 
-The Silero network itself (`silero_vad` package or `torch.hub` download,
-`core/vocal_pause_detector.py:74-123`) cannot be obtained offline, so the default `inference_fn`
-here is `EnergyGateVad`: a HIP framed-RMS kernel over 512-samples-at-16-kHz-equivalent windows
-followed by Silero's published hysteresis post-processing with the reference's parameters
-(`vocal_pause_detector.py:208-213`: threshold 0.35, min speech 250 ms, min silence 700 ms,
-pad 150 ms).  Operators with Silero weights inject their own `inference_fn`, exactly as the
-reference allows (`silero_chunk_vad.py:34`).
+The default `inference_fn` is `detectors.silero_vad.default_vad`: the Silero VAD network on the HIP kernels
+(`SileroHipVad`: 44.1 -> 16 kHz resampling, 4096 bucket padding, 512-sample windows with state carry,
+`vocal_pause_detector.py:175-296`) when a weights file is configured (`advanced_vad.silero_weights_path` /
+`AUDIOCUT_SILERO_WEIGHTS`; the `silero_vad` package and its weights cannot be obtained offline), else the
+explicit NO-WEIGHTS mode `EnergyGateVad`: a HIP framed-RMS kernel over 512-samples-at-16-kHz-equivalent windows.
+Both end in Silero's published hysteresis post-processing with the reference's parameters
+(`vocal_pause_detector.py:208-213`: threshold 0.35, min speech 250 ms, min silence 700 ms, pad 150 ms).
+Callers may still inject their own `inference_fn`, exactly as the reference allows (`silero_chunk_vad.py:34`).
 """
 from __future__ import annotations
 
@@ -96,6 +97,10 @@ class EnergyGateVad:
         self.floor_db, self.ceil_db = floor_db, ceil_db
         self._ctx = ctx
 
+    def precompute(self, packed_dev, offsets: Sequence[int], lengths: Sequence[int]) -> List["PrecomputedChunk"]:
+        """The batched interface `EnhancedVocalSeparator` looks for (shared with `SileroHipVad`)."""
+        return self.batch_rms(packed_dev, offsets, lengths)
+
     def batch_rms(self, packed_dev, offsets: Sequence[int], lengths: Sequence[int]) -> List["PrecomputedChunk"]:
         """All chunks of a track in ONE launch and one download: `packed_dev` holds the chunks back to back."""
         ctx = self._ctx or _native.Context()
@@ -148,7 +153,8 @@ class SileroChunkVAD:
 
     def _ensure_inference_fn(self) -> VadFn:
         if self.inference_fn is None:
-            self.inference_fn = EnergyGateVad(self.sample_rate)
+            from .silero_vad import default_vad
+            self.inference_fn = default_vad(self.sample_rate)
         return self.inference_fn
 
     def process_chunk(self, plan: ChunkPlan, vocal_chunk, sr: int, *, stream=None) -> None:

@@ -309,6 +309,36 @@ int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, cons
 int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                         int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
 
+/* ---- Silero VAD (vocal_pause_detector.py:175-296 behind silero_chunk_vad.py:56-117) ----------------------- */
+
+/* ac_resample_poly for n_seg independent segments of one packed buffer in one launch (every chunk's 44.1 kHz -> 16 kHz
+ * resampling, vocal_pause_detector.py:189): segment s = x[in_off[s] .. + in_len[s]) is resampled on its own (zero extension at
+ * its edges) into out[out_off[s] .. + out_len[s]); out_off[s + 1] - out_off[s] >= out_len[s], the slack (the 4096-sample bucket
+ * padding of :192-196) is left untouched - the caller zeroes `out`.  in_off / in_len / out_off / out_len: device int64 [n_seg],
+ * out_off increasing; n_out_total = out_off[n_seg - 1] + padded length of the last segment.  h as for ac_resample_poly. */
+int ac_resample_poly_segments(ac_ctx* ctx, const float* x, const int64_t* in_off, const int64_t* in_len, const int64_t* out_off,
+                              const int64_t* out_len, int n_seg, int up, int down, const float* h, int64_t hlen,
+                              int64_t n_pre_remove, float* out, int64_t n_out_total, void* stream);
+
+/* The Silero VAD v5 16 kHz network up to the LSTM's input gates, for n_windows independent windows (8 per workgroup):
+ * window w = 64 samples of context + 512 samples starting at x16[win_start[w]] (a chunk's FIRST window is flagged by
+ * win_start = -(index) - 1: its context is zeros), reflect-padded by 64, STFT as a stride-128 convolution with
+ * forward_basis_buffer (basis_t [256][258], transposed), magnitude, Conv1d(129,128,3) / (128,64,3,s2) / (64,64,3,s2) /
+ * (64,128,3) each + ReLU (weights as [c_in * 3 + tap][c_out]), then gates_x[w][512] = weight_ih feat + bias_ih + bias_hh
+ * (wih_t [128][512], bias_sum [512]).  x16 must be readable 64 samples before every non-first window and 576 after its start. */
+int ac_silero_frontend(ac_ctx* ctx, const float* x16, const int64_t* win_start, int n_windows, const float* basis_t,
+                       const float* c1, const float* b1, const float* c2, const float* b2, const float* c3, const float* b3,
+                       const float* c4, const float* b4, const float* wih_t, const float* bias_sum, float* gates_x, void* stream);
+
+/* LSTMCell(128, 128) over the windows of each chunk (state zero at the chunk's first window, as silero_vad's
+ * get_speech_timestamps resets it per call): chunk s owns windows seg_first_window[s] .. + seg_window_count[s] of gates_x;
+ * h_out[w][128] = hidden state after window w.  whh_t [128][512] = weight_hh transposed.  One workgroup per chunk. */
+int ac_silero_lstm(ac_ctx* ctx, const float* gates_x, const int* seg_first_window, const int* seg_window_count, int n_seg,
+                   const float* whh_t, float* h_out, void* stream);
+
+/* probs[w] = sigmoid(b_out + sum_j w_out[j] relu(h[w][j])): the decoder's ReLU + Conv1d(128, 1, 1) + Sigmoid. */
+int ac_silero_out(ac_ctx* ctx, const float* h, const float* w_out, float b_out, int n_windows, float* probs, void* stream);
+
 /* ---- host-side sequential helper (runs on the CPU; pointers are HOST pointers) ------------- */
 
 /* librosa.beat.__beat_track_dp: the O(n * period) dynamic programme over the local score

@@ -109,3 +109,10 @@ def write_tfc_tdf_onnx(path, w, spec, *, fold_conv_bn: bool = False, raw: bool =
     model = _vi((1 << 3) | 0) + _vi(8) + _ld(2, b"audio-cut-test-writer") + _ld(7, graph)
     with open(path, "wb") as fh:
         fh.write(model)
+
+
+def write_named_initializers_onnx(path, tensors) -> None:
+    """A ModelProto whose graph holds only float32 initializers under the given names (the Silero VAD loader test)."""
+    graph = b"".join(_ld(5, _tensor(name, np.asarray(arr, dtype=np.float32))) for name, arr in tensors.items())
+    with open(path, "wb") as fh:
+        fh.write(_vi((1 << 3) | 0) + _vi(8) + _ld(7, graph))           # ir_version = 8, graph
