@@ -13,7 +13,7 @@ from typing import Dict
 import numpy as np
 
 
-def synth_silero_weights(seed: int = 0) -> Dict[str, np.ndarray]:
+def synth_silero_weights(seed: int = 0, calib: str = "voice") -> Dict[str, np.ndarray]:
     from audio_cut_amd.testing import signals
     from oracle import silero as OS
     rng = np.random.default_rng(seed)
@@ -35,7 +35,9 @@ def synth_silero_weights(seed: int = 0) -> Dict[str, np.ndarray]:
     w["decoder.decoder.2.weight"] = (rng.standard_normal((1, 128, 1)) / np.sqrt(128)).astype(np.float32)
     w["decoder.decoder.2.bias"] = np.zeros(1, np.float32)
     # calibrate the output layer: logit -> a * logit + b
-    clip = OS.resample_to_16k(signals.voice_with_rests(12.0, seed=1000 + seed), 44100)
+    # "voice": a sung line at its natural level; "bursts": tone bursts / exact silences at the level a separated stem has
+    clip44 = signals.voice_with_rests(12.0, seed=1000 + seed) if calib == "voice" else 0.35 * signals.c1_sine_silence(12.0, seed=1000 + seed)
+    clip = OS.resample_to_16k(clip44, 44100)
     p = OS.silero_probs(w, clip).astype(np.float64)
     logit = np.log(np.clip(p, 1e-7, 1 - 1e-7) / np.clip(1 - p, 1e-7, 1))
     nw = len(p)

@@ -94,9 +94,9 @@ def test_separator_with_silero_vad_end_to_end(hip_ctx, tmp_path):
     from audio_cut_amd.separation.backends import MDX23HipBackend
     from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
     from oracle import e2e as OE, refine as OR, silero as OS
-    sw = synth_silero_weights(1)
+    sw = synth_silero_weights(0, calib="bursts")
     np.savez(tmp_path / "silero.npz", **sw)
-    mix = signals.c2_song(27.0, seed=21)
+    mix = signals.c1_sine_silence(27.0, seed=3)          # bursts and exact silences: the separated stem keeps the pattern, the VAD segments it
     weights = synth_weights(TfcTdfSpec(), seed=0)
     backend = MDX23HipBackend(weights=weights, ctx=hip_ctx)
     backend.load_model()
@@ -110,7 +110,7 @@ def test_separator_with_silero_vad_end_to_end(hip_ctx, tmp_path):
         C.restore(saved)
     OR.LEGACY_PROMOTION = True
     ref = OE.run_track(mix, SR, weights, vad_fn=OS.silero_vad_fn(SR, sw))
-    assert res["vad_segments"] == ref.vad_segments and len(ref.vad_segments) >= 1
+    assert res["vad_segments"] == ref.vad_segments and len(ref.vad_segments) >= 4
     assert [p.cut_point for p in res["pauses"]] == [p.cut_point for p in ref.pauses]
     assert res["sample_boundaries"] == ref.sample_boundaries
     assert res["cuts_samples"] == ref.policy.cuts
