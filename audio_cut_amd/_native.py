@@ -88,7 +88,8 @@ SIGNATURES = {
     "ac_stft2048_spectral": (C.c_int, [_P, _P, _I64, _I, C.c_double, _P, _P, _I64, _P]),
     "ac_segment_frame_rms": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I, _I, _I, _I, _P, _I64, _P]),
     "ac_segment_sumsq_peak": (C.c_int, [_P, _P, _I64, _P, _P, _I, _P, _P, _P]),
-    "ac_local_valley": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "ac_local_valley_tiles": (C.c_int, [_I, _I]),
+    "ac_local_valley": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "ac_resample_poly": (C.c_int, [_P, _P, _I64, _I, _I, _P, _I64, _I64, _P, _I64, _P]),
     "ac_pack_pcm24": (C.c_int, [_P, _P, _I64, _P, _P]),
     "ac_resample_poly_segments": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I64, _I64, _P, _I64, _P]),
@@ -347,7 +348,10 @@ class Context:
         od = torch.empty(k, dtype=torch.float64, device=self.device)
         md = torch.empty(k, dtype=torch.float64, device=self.device)
         mi = torch.empty(k, dtype=torch.int64, device=self.device)
-        _check(self.lib.ac_local_valley(self._h, _ptr(x), x.numel(), _ptr(c), k, int(radius), int(win), _ptr(od), _ptr(md), _ptr(mi), _stream()))
+        nt = int(self.lib.ac_local_valley_tiles(int(radius), int(win)))
+        pv = torch.empty(k * nt, dtype=torch.float64, device=self.device); pi = torch.empty(k * nt, dtype=torch.int64, device=self.device)
+        _check(self.lib.ac_local_valley(self._h, _ptr(x), x.numel(), _ptr(c), k, int(radius), int(win), _ptr(od), _ptr(md), _ptr(mi),
+                                        _ptr(pv), _ptr(pi), _stream()))
         return od.cpu().numpy(), md.cpu().numpy(), mi.cpu().numpy()
 
     # -- multi-feature detector branch ---------------------------------------------

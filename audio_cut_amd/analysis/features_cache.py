@@ -155,7 +155,7 @@ class ChunkFeatureBuilder:
         return ctx.to_device(np.concatenate(self._chunks)), bounds
 
     def _chunk_series(self):
-        """Per-chunk rms / flatness / onset envelope for every frame of every chunk (three launches)."""
+        """Per-chunk rms / flatness / onset envelope for every frame of every chunk (four launches for the whole track)."""
         ctx = self._context()
         buf, bounds = self._device_buffer()
         hop, fl = self.hop_length, self.frame_length
@@ -168,11 +168,10 @@ class ChunkFeatureBuilder:
         fc = ctx.to_device(np.concatenate(centers)); flo = ctx.to_device(np.concatenate(los)); fhi = ctx.to_device(np.concatenate(his))
         flat, mel = ctx.stft2048_features(buf, hop, want_flat=True, want_mel=True, frame_center=fc, frame_lo=flo, frame_hi=fhi)
         env = ctx.onset_strength(mel, hop, "mean", group_start=groups)
-        # RMS (frame 4410) of a chunk with chunk-local zero padding: evaluate per chunk on its slice
-        rms_parts = [ctx.frame_rms(buf[lo:hi], fl, hop) for lo, hi in bounds]
-        import torch
-        rms = torch.cat(rms_parts)
-        return rms.cpu().numpy(), flat.cpu().numpy(), env.cpu().numpy(), groups
+        # RMS (frame 4410) of every chunk with chunk-local zero padding, all chunks in one launch (same per-frame arithmetic
+        # as ac_frame_rms on the chunk's slice: lane i sums elements i, i + 64, ... in float64)
+        rms = np.concatenate(ctx.segment_frame_rms(buf, [lo for lo, _ in bounds], [hi for _, hi in bounds], fl, hop, center=True))
+        return rms, flat.cpu().numpy(), env.cpu().numpy(), groups
 
     def finalize(self, full_mix_wave: np.ndarray) -> TrackFeatureCache:
         if not self._plans:

@@ -381,7 +381,8 @@ extern "C" int ac_quiet_guard_slow(ac_ctx* ctx, const float* x, int64_t n, const
 // =================================================================================================
 #define PC_RUN 16
 
-__device__ void seg_env_argmin(const float* __restrict__ x, int64_t a, int m, int W, double& best, long long& best_i) {
+__device__ void seg_env_argmin(const float* __restrict__ x, int64_t a, int m, int W, double& best, long long& best_i,
+                               int tile_first = 0, int tile_stride = 1) {
     // per-thread partial argmin over outputs [0, max(m, W)) of the 'same' convolution of
     // x[a : a+m)^2 (float32 squares) with ones(W)/W; envelope compared as float32 like the reference.
     // output i sums samples j in [i + off - W + 1, i + off] clipped to [0, m).
@@ -389,7 +390,8 @@ __device__ void seg_env_argmin(const float* __restrict__ x, int64_t a, int m, in
     const int off = ((m < W ? m : W) - 1) / 2;          // (min(m, W) - 1) // 2
     const float invf = 1.0f / (float)W;
     best = INFINITY; best_i = NQ_INF;
-    for (int tile = 0; tile < out_len; tile += 256 * PC_RUN) {
+    // tiles of 256 * PC_RUN outputs; a caller that splits a segment over workgroups takes tiles tile_first, + tile_stride, ...
+    for (int tile = tile_first * 256 * PC_RUN; tile < out_len; tile += tile_stride * 256 * PC_RUN) {
         const int o0 = tile + (int)threadIdx.x * PC_RUN;
         const int o1 = min(out_len, o0 + PC_RUN);
         if (o0 >= o1) continue;
@@ -416,6 +418,29 @@ __device__ void seg_env_argmin(const float* __restrict__ x, int64_t a, int m, in
     }
 }
 
+// Phase 1 of a pause's cut point: the argmin of the envelope over the whole pause, split over PC_SPLIT workgroups (a long pause
+// used to keep one CU busy for milliseconds while the rest of the chip idled).  The envelope is a non-negative float32 and the
+// rule is "first minimum", so (float bits << 32 | output index) under an unsigned 64-bit atomicMin IS the argmin.
+#define PC_SPLIT 64
+__global__ __launch_bounds__(256) void k_pause_argmin(const float* __restrict__ x, const int64_t* __restrict__ pa,
+                                                      const int64_t* __restrict__ pb, int win, unsigned long long* __restrict__ key) {
+    __shared__ double s_v[4];
+    __shared__ long long s_i[4];
+    const int q = blockIdx.x;
+    const int64_t a = pa[q], b = pb[q];
+    const int m = (int)(b - a);
+    if (m <= 1) return;
+    const int out_len = m >= win ? m : win;
+    if ((int)blockIdx.y * 256 * PC_RUN >= out_len) return;
+    double v; long long bi;
+    seg_env_argmin(x, a, m, win, v, bi, (int)blockIdx.y, PC_SPLIT);
+    block_argmin_256(v, bi, s_v, s_i);
+    if (threadIdx.x == 0 && bi != NQ_INF) {
+        const float e = (float)v;                                   // the envelope values are float32 (exactly representable)
+        atomicMin(&key[q], ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(unsigned)bi);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pause_cut(const float* __restrict__ x, int64_t n, const int64_t* __restrict__ pa,
                                                    const int64_t* __restrict__ pb, int win, int guard,
                                                    int64_t* __restrict__ cut_out, int64_t* __restrict__ aux_out) {
@@ -428,8 +453,9 @@ __global__ __launch_bounds__(256) void k_pause_cut(const float* __restrict__ x, 
     const int m = (int)(b - a);
     if (m <= 1) { if (threadIdx.x == 0) { cut_out[q] = -1; aux_out[2 * q] = 0; aux_out[2 * q + 1] = 0; } return; }
     double v; long long bi;
-    seg_env_argmin(x, a, m, win, v, bi);
-    block_argmin_256(v, bi, s_v, s_i);
+    const unsigned long long key = (unsigned long long)cut_out[q];          // phase 1's packed (envelope, index); all ones = no finite value
+    __syncthreads();                                                        // everyone has read the key before thread 0 overwrites it
+    bi = (key == ~0ULL) ? NQ_INF : (long long)(key & 0xFFFFFFFFULL);
     long long cut = a + (bi == NQ_INF ? 0 : bi);
     if (guard > 0) {
         const int64_t g_end = min(n, (int64_t)cut + guard);
@@ -462,6 +488,9 @@ extern "C" int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const
                                    int guard, int64_t* cut_out, int64_t* aux_out, void* stream) {
     AC_REQUIRE(ctx && x && a && b && cut_out && aux_out, "null pointer");
     AC_REQUIRE(n > 0 && k > 0 && win >= 2 && guard >= 0, "sizes must be positive");
+    // cut_out doubles as the phase-1 key array: all ones, atomicMin'ed by k_pause_argmin, consumed and overwritten by k_pause_cut
+    AC_CHECK_HIP(hipMemsetAsync(cut_out, 0xFF, (size_t)k * sizeof(int64_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_pause_argmin, dim3(k, PC_SPLIT), dim3(256), 0, (hipStream_t)stream, x, a, b, win, (unsigned long long*)cut_out);
     hipLaunchKernelGGL(k_pause_cut, dim3(k), dim3(256), 0, (hipStream_t)stream, x, n, a, b, win, guard, cut_out, aux_out);
     AC_LAUNCH_CHECK();
     return AC_OK;
@@ -512,29 +541,26 @@ extern "C" int ac_segment_frame_rms(ac_ctx* ctx, const float* x, int64_t n, cons
 #define NQ_INF_I 0x7fffffffffffffffLL
 #define LV_MAX_WIN 2048
 
+// grid (boundary, tile of LV_TILE outputs): a +-500 ms search is 43 tiles, which one workgroup per boundary used to walk alone
 __global__ __launch_bounds__(256) void k_local_valley(const float* __restrict__ x, int64_t n, const int64_t* __restrict__ centers,
-                                                      int radius, int win, double* __restrict__ orig_db, double* __restrict__ min_db,
-                                                      int64_t* __restrict__ min_idx) {
+                                                      int radius, int win, int n_tiles, double* __restrict__ orig_db,
+                                                      double* __restrict__ part_v, int64_t* __restrict__ part_i) {
     __shared__ double s_sq[LV_TILE + LV_MAX_WIN];
     __shared__ double s_bv[4];
     __shared__ long long s_bi[4];
-    const int k = blockIdx.x;
+    const int k = blockIdx.x, tile = blockIdx.y;
     const int64_t c = centers[k];
     const int64_t a = c - radius < 0 ? 0 : c - radius;
     const int64_t b = c + radius > n ? n : c + radius;
     const int64_t len = b - a;
-    if (len <= win) {                                // `if segment.size <= win: continue`
-        if (threadIdx.x == 0) { orig_db[k] = 0.0; min_db[k] = 0.0; min_idx[k] = -1; }
-        return;
-    }
-    const int64_t m = len - win + 1;                 // 'valid' outputs
-    int64_t o = c - a - win / 2;
-    o = o < 0 ? 0 : (o > m - 1 ? m - 1 : o);
-    const double inv = 1.0 / (double)win;
     double best = INFINITY; long long besti = NQ_INF_I;
-    for (int64_t t0 = 0; t0 < m; t0 += LV_TILE) {
+    const int64_t m = len - win + 1;                 // 'valid' outputs (<= 0: `if segment.size <= win: continue`)
+    const int64_t t0 = (int64_t)tile * LV_TILE;
+    if (len > win && t0 < m) {
+        int64_t o = c - a - win / 2;
+        o = o < 0 ? 0 : (o > m - 1 ? m - 1 : o);
+        const double inv = 1.0 / (double)win;
         const int cnt = (int)((m - t0) < LV_TILE ? (m - t0) : LV_TILE);
-        __syncthreads();
         for (int i = threadIdx.x; i < cnt + win - 1; i += 256) { const double v = (double)x[a + t0 + i]; s_sq[i] = v * v; }
         __syncthreads();
         for (int i = threadIdx.x; i < cnt; i += 256) {
@@ -556,16 +582,41 @@ __global__ __launch_bounds__(256) void k_local_valley(const float* __restrict__ 
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w)
             if (s_bv[w] < best || (s_bv[w] == best && s_bi[w] < besti)) { best = s_bv[w]; besti = s_bi[w]; }
-        min_db[k] = best; min_idx[k] = besti;
+        part_v[(size_t)k * n_tiles + tile] = best; part_i[(size_t)k * n_tiles + tile] = besti;
     }
 }
 
+// first minimum over a boundary's tiles (tiles are in index order: a strict `<` keeps the earliest)
+__global__ __launch_bounds__(64) void k_local_valley_pick(const int64_t* __restrict__ centers, int n_k, int64_t n, int radius, int win, int n_tiles,
+                                                          const double* __restrict__ part_v, const int64_t* __restrict__ part_i,
+                                                          double* __restrict__ orig_db, double* __restrict__ min_db,
+                                                          int64_t* __restrict__ min_idx) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_k) return;
+    const int64_t c = centers[k];
+    const int64_t a = c - radius < 0 ? 0 : c - radius;
+    const int64_t b = c + radius > n ? n : c + radius;
+    if (b - a <= win) { orig_db[k] = 0.0; min_db[k] = 0.0; min_idx[k] = -1; return; }
+    double best = INFINITY; long long besti = NQ_INF_I;
+    for (int t = 0; t < n_tiles; ++t) {
+        const double v = part_v[(size_t)k * n_tiles + t]; const long long i = part_i[(size_t)k * n_tiles + t];
+        if (v < best || (v == best && i < besti)) { best = v; besti = i; }
+    }
+    min_db[k] = best; min_idx[k] = besti;
+}
+
+extern "C" int ac_local_valley_tiles(int radius, int win) { const int m = 2 * radius - win + 1; return m <= 0 ? 1 : (m + LV_TILE - 1) / LV_TILE; }
+
 extern "C" int ac_local_valley(ac_ctx* ctx, const float* x, int64_t n, const int64_t* centers, int k, int radius, int win,
-                                double* orig_db, double* min_db, int64_t* min_idx, void* stream) {
-    AC_REQUIRE(ctx && x && centers && orig_db && min_db && min_idx, "null pointer");
+                                double* orig_db, double* min_db, int64_t* min_idx, double* part_v, int64_t* part_i, void* stream) {
+    AC_REQUIRE(ctx && x && centers && orig_db && min_db && min_idx && part_v && part_i, "null pointer");
     AC_REQUIRE(n > 0 && k > 0 && radius > 0 && win > 0 && win <= LV_MAX_WIN, "0 < win <= 2048, radius > 0");
-    hipLaunchKernelGGL(k_local_valley, dim3((unsigned)k), dim3(256), 0, (hipStream_t)stream, x, n, centers, radius, win, orig_db,
-                       min_db, min_idx);
+    const int n_tiles = ac_local_valley_tiles(radius, win);
+    AC_REQUIRE(n_tiles <= 65535, "radius too large");
+    hipLaunchKernelGGL(k_local_valley, dim3((unsigned)k, (unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, x, n, centers, radius, win,
+                       n_tiles, orig_db, part_v, part_i);
+    hipLaunchKernelGGL(k_local_valley_pick, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, (hipStream_t)stream, centers, k, n, radius,
+                       win, n_tiles, part_v, part_i, orig_db, min_db, min_idx);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

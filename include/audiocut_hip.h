@@ -264,9 +264,11 @@ int ac_segment_frame_rms(ac_ctx* ctx, const float* x, int64_t n, const int64_t* 
 /* `_refine_boundaries_local_valley` (core/seamless_splitter.py:2646-2661): for boundary c the window [c - radius, c + radius)
  * clipped to the signal, float64 'valid' moving mean of x^2 over `win`, dB = 20 log10(sqrt(mean + 1e-12) + 1e-12);
  * orig_db[k] = dB at clip(c - start - win/2), min_db / min_idx[k] = first minimum (index into the 'valid' series;
- * -1 when the window is not longer than `win`). */
+ * -1 when the window is not longer than `win`).  The search of one boundary is split over ac_local_valley_tiles(radius, win)
+ * workgroups (1024 outputs each); part_v / part_i [k * that many] are scratch for their partial minima. */
+int ac_local_valley_tiles(int radius, int win);
 int ac_local_valley(ac_ctx* ctx, const float* x, int64_t n, const int64_t* centers, int k, int radius, int win, double* orig_db,
-                    double* min_db, int64_t* min_idx, void* stream);
+                    double* min_db, int64_t* min_idx, double* part_v, int64_t* part_i, void* stream);
 
 /* per-segment sum of x^2 (float64) and peak |x| over [seg_start[s], seg_end[s]) (host bounds inside [0, n]) as 16
  * partials per segment (sumsq / peak are [n_seg][16]; the caller adds / maxes them in order):
