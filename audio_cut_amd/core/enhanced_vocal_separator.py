@@ -171,8 +171,8 @@ class EnhancedVocalSeparator:
         plans = gpu_context.plans
         total = len(audio)
         timings: Dict[str, float] = {}
-        torch.cuda.reset_peak_memory_stats(hip.device)
-        backend.reset_performance_metrics()
+        # per-call metrics only: under batch.TrackPipeline another track shares this backend and this device, so nothing
+        # backend- or device-global is reset here (the stage timings of THIS call come back through `timings`)
         t0 = time.perf_counter()
         if audio_dev is not None:
             if audio_dev.numel() != total or audio_dev.dtype != torch.float32:
@@ -263,16 +263,15 @@ class EnhancedVocalSeparator:
         vocal = vocal_h.numpy()
         inst = inst_h.numpy() if has_inst else None
 
-        perf = backend.get_performance_metrics(reset=True)
         gm = gpu_context.gpu_meta
         gm["gpu_pipeline_processed_chunks"] = len(sep.chunk_ranges)
         gm["gpu_pipeline_used"] = bool(gpu_context.enabled)
         gm["silero_vad_segments"] = len(vad_segments)
         gm["gpu_pipeline_h2d_ms"] = float(h2d_ms)
         gm["gpu_pipeline_dtoh_ms"] = float(dtoh_ms)
-        gm["gpu_pipeline_compute_ms"] = float(perf.get("compute_ms", 0.0))
-        gm["gpu_pipeline_peak_mem_bytes"] = float(torch.cuda.max_memory_allocated(hip.device))
-        gm["gpu_pipeline_chunk_invocations"] = int(perf.get("chunks", 0.0))
+        gm["gpu_pipeline_compute_ms"] = float(timings.get("stft_ms", 0.0) + timings.get("unet_ms", 0.0) + timings.get("istft_ms", 0.0))
+        gm["gpu_pipeline_peak_mem_bytes"] = float(torch.cuda.max_memory_allocated(hip.device))     # device-wide high-water mark since process start
+        gm["gpu_pipeline_chunk_invocations"] = len(sep.chunk_ranges)
         gm["mdx23_output_type"] = backend.get_output_type()
         gm["gpu_pipeline_stage_ms"] = dict(timings)
         gpu_context.capture_device_metrics()

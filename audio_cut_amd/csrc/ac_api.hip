@@ -73,15 +73,8 @@ static int upload(T** dst, const std::vector<T>& v) {
     return AC_OK;
 }
 
-extern "C" int ac_ctx_create(int device, ac_ctx** out) {
-    AC_REQUIRE(out != nullptr, "out pointer");
-    int count = 0;
-    AC_CHECK_HIP(hipGetDeviceCount(&count));
-    AC_REQUIRE(device >= 0 && device < count, "device index");
-    AC_CHECK_HIP(hipSetDevice(device));
-    ac_ctx* c = (ac_ctx*)calloc(1, sizeof(ac_ctx));
-    if (!c) { ac_set_error("out of host memory"); return AC_E_NOMEM; }
-    c->device = device;
+// everything after the calloc: a failure leaves a partly filled context that the caller (ac_ctx_create) destroys
+static int ctx_fill(ac_ctx* c, int device) {
     AC_CHECK_HIP(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device));
     if (c->n_cu <= 0) c->n_cu = 256;
     int rc;
@@ -114,15 +107,39 @@ extern "C" int ac_ctx_create(int device, ac_ctx** out) {
             for (int n = 0; n < N; ++n) env[t * H + n] += hw[n] * hw[n];
         if ((rc = upload(&c->ola_env6144, env))) return rc;
     }
-    *out = c;
     return AC_OK;
+}
+
+extern "C" int ac_ctx_create(int device, ac_ctx** out) {
+    AC_REQUIRE(out != nullptr, "out pointer");
+    *out = nullptr;
+    int count = 0;
+    AC_CHECK_HIP(hipGetDeviceCount(&count));
+    AC_REQUIRE(device >= 0 && device < count, "device index");
+    int previous = -1;
+    (void)hipGetDevice(&previous);                 // the caller's current device is restored on every path
+    AC_CHECK_HIP(hipSetDevice(device));
+    ac_ctx* c = (ac_ctx*)calloc(1, sizeof(ac_ctx));
+    int rc = AC_OK;
+    if (!c) { ac_set_error("out of host memory"); rc = AC_E_NOMEM; }
+    else {
+        c->device = device;
+        rc = ctx_fill(c, device);
+        if (rc != AC_OK) { ac_ctx_destroy(c); c = nullptr; }     // hipFree(nullptr) is a no-op: frees whatever was uploaded
+    }
+    if (previous >= 0 && previous != device) (void)hipSetDevice(previous);
+    if (rc == AC_OK) *out = c;
+    return rc;
 }
 
 extern "C" int ac_ctx_destroy(ac_ctx* c) {
     if (!c) return AC_OK;
+    int previous = -1;
+    (void)hipGetDevice(&previous);
     (void)hipSetDevice(c->device);
     (void)hipFree(c->tw2048); (void)hipFree(c->hann2048); (void)hipFree(c->mel_w); (void)hipFree(c->mel_lo); (void)hipFree(c->mel_hi);
     (void)hipFree(c->tw6144); (void)hipFree(c->hann6144); (void)hipFree(c->ola_env6144);
+    if (previous >= 0 && previous != c->device) (void)hipSetDevice(previous);
     free(c);
     return AC_OK;
 }
