@@ -93,9 +93,20 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
         const int gy = y0 + a_row - 1, gx = x0 - 4 + 4 * a_qd;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_src = gy * W + gx;
     }
+    // out-of-image / idle slots load from a clamped in-bounds address and are zeroed when staged: no divergent branch around the
+    // loads (6 fewer spilled registers in the 48-channel variant).  Activation loads run one stage ahead; two stages ahead (two
+    // register sets, counted vmcnt) was measured 2-12 % SLOWER on every level (profiles/r02g_conv_prefetch_depth.log).
+    const int a_ld = a_src >= 0 ? a_src : 0;
     float4 pre_x[4];
 
-    auto prefetch = [&](int cb) {
+    auto prefetch_x = [&](int cb, float4 (&pxr)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = cb * W9_CB + a_c4 * 4 + q;
+            pxr[q] = *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_ld);
+        }
+    };
+    auto prefetch_w = [&](int cb) {
         const f16x8* wcb = wbase + (size_t)cb * 3 * W9_KFR;
         f16x8* dst = (cb & 1) ? s_w1 : s_w0;
         const bool third = ((cb & 3) == 3) || cb == n_cb - 1;                       // this stage carries the shared tap-8 k-step
@@ -105,24 +116,21 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
             const int inst = wave + 4 * i;
             if (inst < n_inst) __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ci = cb * W9_CB + a_c4 * 4 + q;
-            pre_x[q] = (a_src >= 0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
     };
 
-    prefetch(0);
+    prefetch_w(0); prefetch_x(0, pre_x);
     for (int cb = 0; cb < n_cb; ++cb) {
+        float4 (&pxr)[4] = pre_x;
         __syncthreads();                 // previous stage fully consumed
         if (a_live) {
-            const float* v4[4] = {&pre_x[0].x, &pre_x[1].x, &pre_x[2].x, &pre_x[3].x};
+            const float zs = a_src >= 0 ? act_s : 0.f;         // zero padding (and the idle slots of a row)
+            const float* v4[4] = {&pxr[0].x, &pxr[1].x, &pxr[2].x, &pxr[3].x};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fminf(fmaxf(v4[q][k] * act_s, -65504.f), 65504.f);
+                    const float v = fminf(fmaxf(v4[q][k] * zs, -65504.f), 65504.f);
                     const _Float16 hv = (_Float16)v;
                     h4[q] = w9_bits(hv);
                     l4[q] = w9_bits((_Float16)(v - (float)hv));
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
         }
         __builtin_amdgcn_s_waitcnt(0);   // this stage's weight fragments have landed
         __syncthreads();
-        if (cb + 1 < n_cb) prefetch(cb + 1);
+        if (cb + 1 < n_cb) { prefetch_w(cb + 1); prefetch_x(cb + 1, pxr); }
         const f16x8* s_w = (cb & 1) ? s_w1 : s_w0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {

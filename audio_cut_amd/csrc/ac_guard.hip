@@ -423,9 +423,11 @@ __device__ void seg_env_argmin(const float* __restrict__ x, int64_t a, int m, in
 // rule is "first minimum", so (float bits << 32 | output index) under an unsigned 64-bit atomicMin IS the argmin.
 #define PC_SPLIT 64
 __global__ __launch_bounds__(256) void k_pause_argmin(const float* __restrict__ x, const int64_t* __restrict__ pa,
-                                                      const int64_t* __restrict__ pb, int win, unsigned long long* __restrict__ key) {
+                                                      const int64_t* __restrict__ pb, int win, unsigned long long* __restrict__ key,
+                                                      unsigned long long* __restrict__ zeros /* aux_out[2 q], zeroed */) {
     __shared__ double s_v[4];
     __shared__ long long s_i[4];
+    __shared__ int s_zero[4];
     const int q = blockIdx.x;
     const int64_t a = pa[q], b = pb[q];
     const int m = (int)(b - a);
@@ -438,6 +440,19 @@ __global__ __launch_bounds__(256) void k_pause_argmin(const float* __restrict__ 
     if (threadIdx.x == 0 && bi != NQ_INF) {
         const float e = (float)v;                                   // the envelope values are float32 (exactly representable)
         atomicMin(&key[q], ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(unsigned)bi);
+    }
+    // exact zeros of the segment (the percentile floor test), over the same tiles
+    int z = 0;
+    for (int tile = (int)blockIdx.y * 256 * PC_RUN; tile < m; tile += PC_SPLIT * 256 * PC_RUN) {
+        const int hi = min(m, tile + 256 * PC_RUN);
+        for (int i = tile + (int)threadIdx.x; i < hi; i += 256) z += (x[a + i] == 0.0f);
+    }
+    for (int off = 32; off > 0; off >>= 1) z += __shfl_down(z, off, AC_WAVE);
+    if ((threadIdx.x & 63) == 0) s_zero[threadIdx.x >> 6] = z;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int zt = s_zero[0] + s_zero[1] + s_zero[2] + s_zero[3];
+        if (zt) atomicAdd(&zeros[2 * q], (unsigned long long)zt);
     }
 }
 
@@ -469,19 +484,11 @@ __global__ __launch_bounds__(256) void k_pause_cut(const float* __restrict__ x, 
             cut = c2;
         }
     }
-    // zeros in |segment| for the percentile floor test
-    int z = 0;
-    for (int i = threadIdx.x; i < m; i += 256) z += (x[a + i] == 0.0f);
-    for (int off = 32; off > 0; off >>= 1) z += __shfl_down(z, off, AC_WAVE);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_zero[threadIdx.x >> 6] = z;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {              // aux_out[2 q] (zeros in the segment) was accumulated by k_pause_argmin
         cut_out[q] = cut;
-        aux_out[2 * q] = s_zero[0] + s_zero[1] + s_zero[2] + s_zero[3];
         aux_out[2 * q + 1] = (x[cut] != 0.0f) ? 1 : 0;
     }
-    (void)s_cut;
+    (void)s_cut; (void)s_zero;
 }
 
 extern "C" int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const int64_t* a, const int64_t* b, int k, int win,
@@ -490,7 +497,9 @@ extern "C" int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const
     AC_REQUIRE(n > 0 && k > 0 && win >= 2 && guard >= 0, "sizes must be positive");
     // cut_out doubles as the phase-1 key array: all ones, atomicMin'ed by k_pause_argmin, consumed and overwritten by k_pause_cut
     AC_CHECK_HIP(hipMemsetAsync(cut_out, 0xFF, (size_t)k * sizeof(int64_t), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_pause_argmin, dim3(k, PC_SPLIT), dim3(256), 0, (hipStream_t)stream, x, a, b, win, (unsigned long long*)cut_out);
+    AC_CHECK_HIP(hipMemsetAsync(aux_out, 0, (size_t)k * 2 * sizeof(int64_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_pause_argmin, dim3(k, PC_SPLIT), dim3(256), 0, (hipStream_t)stream, x, a, b, win, (unsigned long long*)cut_out,
+                       (unsigned long long*)aux_out);
     hipLaunchKernelGGL(k_pause_cut, dim3(k), dim3(256), 0, (hipStream_t)stream, x, n, a, b, win, guard, cut_out, aux_out);
     AC_LAUNCH_CHECK();
     return AC_OK;
