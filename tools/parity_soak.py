@@ -1,5 +1,5 @@
 """Parity soak: the GPU path against the CPU oracle, live, on tracks / weights no fixture covers.
-usage: python scratch/parity_soak.py "dur,song_seed,weight_seed[,generator]" ...   (one progress line per case)"""
+usage: python tools/parity_soak.py "dur,song_seed,weight_seed[,generator]" ...   (one progress line per case)"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 torch.set_num_threads(16)
