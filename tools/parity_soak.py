@@ -36,5 +36,15 @@ for arg in sys.argv[1:]:
           f"manifest cuts {len(cuts_ref)} pauses {len(ref.pauses)} | exact={ok} stem_err={stem:.2e} rms_series_rel={rms:.2e} | gpu {tg:.2f}s oracle {to:.0f}s", flush=True)
     if not ok:
         print("  gpu   :", r["sample_boundaries"], r["cuts_samples"]); print("  oracle:", ref.sample_boundaries, cuts_ref)
+        # how close was each moved decision?  The guard takes argmin of the 80 ms moving-RMS dB series (refine.py:184-214): compare
+        # the ORACLE's own series at the two indices.  A difference of ~1e-12 dB means the reference's decision was a tie on
+        # numerical dust (digital silence: the mean square is far below the 1e-12 epsilon inside the logarithm).
+        if len(r["sample_boundaries"]) == len(ref.sample_boundaries):
+            for g_i, o_i in zip(r["sample_boundaries"], ref.sample_boundaries):
+                if g_i != o_i:
+                    lo = max(0, min(g_i, o_i) - 30000); hi = min(len(mix), max(g_i, o_i) + 30000)
+                    dv = OR.moving_meansq_db(ref.vocal[lo:hi], 3528); dm = OR.moving_meansq_db(mix[lo:hi], 3528)
+                    print(f"    boundary {o_i} (oracle) vs {g_i} (gpu): oracle vocal dB differs by {abs(dv[g_i - lo] - dv[o_i - lo]):.3e}, "
+                          f"mix dB by {abs(dm[g_i - lo] - dm[o_i - lo]):.3e}; vocal level there {dv[o_i - lo]:.6f} dB, |vocal| {abs(float(ref.vocal[o_i])):.2e}, |mix| {abs(float(mix[o_i])):.2e}")
     del backend, sp
 print("ALL EXACT" if ok_all else "MISMATCH")

@@ -1,0 +1,19 @@
+"""Control for the two-processes-on-one-GPU irreproducibility: a chain of PURE PyTorch ops (no kernel of this repo), queued without
+host synchronisation, hashed at the end.  If this differs between repetitions too, the platform - not this library - is the cause."""
+import sys, hashlib, torch, torch.nn.functional as F
+rank = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(rank)
+x0 = torch.randn(16, 48, 256, 1024, generator=g).to(dev)
+ws = [(torch.randn(48, 48, 3, 3, generator=g) / 20).to(dev) for _ in range(8)]
+lin = (torch.randn(1024, 1024, generator=g) / 32).to(dev)
+def once():
+    x = x0
+    for i in range(24):
+        x = F.relu(F.conv2d(x, ws[i % 8], padding=1))
+        if i % 3 == 2:
+            x = x + F.relu(F.linear(x, lin))
+            x = x / (x.abs().amax() + 1e-6)
+    return hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest()[:10]
+ref = once(); out = [once() for _ in range(reps)]
+print(rank, "torch-only ref", ref, "differing:", sum(o != ref for o in out), "of", reps, out, flush=True)
