@@ -512,8 +512,8 @@ class Context:
     # -- MDX23 ---------------------------------------------------------------------------------------
     def mdx_stft(self, track: torch.Tensor, chunk_start: torch.Tensor, chunk_len: torch.Tensor,
                  win_index: torch.Tensor, out: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`amax` [n_items, 32] float32, zeroed by the caller: receives max |spectrogram| per item and block of 8 frames (the first
-        conv's time-local activation scale)."""
+        """`amax` [n_items, 256] float32, zeroed by the caller: receives max |spectrogram| per item and frame (the first conv's
+        time-local activation scale)."""
         self._chk_f32(track)
         n_items = chunk_start.numel()
         if out is None:
@@ -551,16 +551,16 @@ class Context:
         return out
 
     # -- U-Net layers (NCHW float32; `in_amax` / `out_amax`: per-item max |x| of the input / output tensor, include/audiocut_hip.h) --
-    AMAX_ROWS = 8       # AC_AMAX_ROWS: rows of the time axis per amax block
+    AMAX_ROWS = 1       # AC_AMAX_ROWS: rows of the time axis per amax entry (one maximum per item and time row)
 
     def _amax_args(self, b: int, in_amax: Optional[torch.Tensor], out_amax: Optional[torch.Tensor], h_in: int, h_out: int):
-        """amax tensors are float32 [batch, H / 8] (H = the tensor's time axis): max |x| per item and block of 8 rows."""
+        """amax tensors are float32 [batch, H] (H = the tensor's time axis): max |x| per item and time row."""
         for t, h in ((in_amax, h_in), (out_amax, h_out)):
             if t is None:
                 continue
             if h % self.AMAX_ROWS or t.dtype != torch.float32 or t.numel() != b * (h // self.AMAX_ROWS) or not t.is_contiguous() \
                     or t.device != self.device:
-                raise NativeError(f"amax tensors must be contiguous float32 [batch, H / 8] on the context's device (H = {h})")
+                raise NativeError(f"amax tensors must be contiguous float32 [batch, H] on the context's device (H = {h})")
         return _ptr(in_amax), _ptr(out_amax)
 
     def _conv3x3(self, fn, name: str, x, w_packed, bias, c_out, w_unscale, relu, out, in_amax, out_amax) -> torch.Tensor:

@@ -69,12 +69,13 @@ __device__ inline float wave_max_f32(float v) {
 // x = xh + xl with xh = f16(x * s), xl = f16(x * s - xh): without s the low part is a float16 subnormal for |x| < 6e-2 and
 // the pair carries an ABSOLUTE error floor of 2^-25 however small the tensor is (decays into silence lose their relative
 // precision, which is where the quiet guard decides).  Every kernel that writes a tensor a split-f16 kernel reads therefore
-// also reduces max|x| per (batch item, block of AC_AMAX_ROWS rows of the time axis H) into `amax[item][H / 8]` (ordered-bits
-// atomicMax, one per wave and block); a reader takes the maximum over the blocks its tile touches, scales by the power of
-// two that puts it in [2^14, 2^15) and folds the inverse into its epilogue.  Power-of-two scaling is exact, so values whose
-// low part is a normal float16 either way round identically; the floor becomes 2^-40 of the LOCAL maximum (a silent stretch
-// between two loud passages keeps float32-class relative accuracy), and nothing saturates below 2^127.
-#define AC_AMAX_ROWS 8
+// also reduces max|x| per (batch item, row of the time axis H) into `amax[item][H]` (ordered-bits atomicMax, one per wave
+// and row); a reader takes the maximum over exactly the rows that enter one accumulation - the 10 patch rows of a 3x3 conv
+// tile, the single time row of a TDF GEMM row, the two input rows of a 2x2 down-sampling pixel - scales by the power of two
+// that puts it in [2^14, 2^15) and folds the inverse into its epilogue.  Power-of-two scaling is exact, so values whose
+// low part is a normal float16 either way round identically; the floor becomes 2^-40 of the LOCAL maximum (the leakage that
+// decays by orders of magnitude per frame next to a loud passage keeps its relative accuracy), nothing saturates below 2^127.
+#define AC_AMAX_ROWS 1
 // amax_item = amax + item * n_blocks (or NULL: no scaling); blocks b0..b1 inclusive, already clamped; all arguments wave-uniform
 __device__ inline float ac_act_scale(const float* __restrict__ amax_item, int b0, int b1, float gain, float offs, float* inv) {
     float s = 1.f;
@@ -95,6 +96,24 @@ __device__ inline float ac_act_scale(const float* __restrict__ amax_item, int b0
     // wave-uniform by construction: keep the two factors in scalar registers
     *inv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(*inv)));
     s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
+    return s;
+}
+// the same for arguments that differ from lane to lane (a GEMM row's own time row)
+__device__ inline float ac_act_scale_lane(const float* __restrict__ amax_item, int b0, int b1, float* inv) {
+    float s = 1.f;
+    *inv = 1.f;
+    if (amax_item) {
+        float a = 0.f;
+        for (int i = b0; i <= b1; ++i) a = fmaxf(a, amax_item[i]);
+        if (a > 0.f && a < 3.0e38f) {
+            int e;
+            (void)frexpf(a, &e);
+            e = 15 - e;
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            s = ldexpf(1.f, e);
+            *inv = ldexpf(1.f, -e);
+        }
+    }
     return s;
 }
 // m = max |v| over this thread's outputs (>= 0; NaNs never enter through fmaxf): wave reduce, one atomic per wave.

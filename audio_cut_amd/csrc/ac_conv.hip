@@ -97,9 +97,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     // time-local power-of-two activation scale (ac_common.h).  FIRST: in_amax is max|spectrogram|; the tensor that is split is the
     // generated relu(w1 x + b1), bounded by amax * max_c sum_j |w1[c][j]| + max_c |b1[c]| (amax_gain, amax_offs from the host)
     float act_inv;
-    const int n_blk = H / AC_AMAX_ROWS, by = y0 / AC_AMAX_ROWS;          // the patch covers rows y0 - 1 .. y0 + 8 = row blocks by - 1 .. by + 1
-    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * n_blk : nullptr, by > 0 ? by - 1 : 0, by + 1 < n_blk ? by + 1 : n_blk - 1,
-                                     amax_gain, amax_offs, &act_inv);
+    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * H : nullptr, y0 > 0 ? y0 - 1 : 0, y0 + CV_TH < H ? y0 + CV_TH : H - 1,
+                                     amax_gain, amax_offs, &act_inv);          // exactly the patch rows y0 - 1 .. y0 + 8
     const float unscale = w_unscale * act_inv;
 
     f32x4 acc[CV_MT][4];
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     }
     // ---- epilogue: accumulators (D[row = (lane>>4)*4 + r][col = lane&15]) -> LDS tile [co][row][x] -> 128-byte row stores
     __syncthreads();                     // all waves done with the stage buffers
-    float vmax = 0.f;
+    float vmax[2] = {0.f, 0.f};          // this wave's two output rows
 #pragma unroll
     for (int m = 0; m < CV_MT; ++m) {
 #pragma unroll
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                 const int co = m * 16 + g * 4 + r;
                 float v = acc[m][q][r] * unscale + bias[cob * CV_COB + co];
                 if (RELU) v = fmaxf(v, 0.f);
-                vmax = fmaxf(vmax, fabsf(v));
+                vmax[q >> 1] = fmaxf(vmax[q >> 1], fabsf(v));
                 s_out[(co * CV_TH + ty) * CV_OUT_STRIDE + tx] = v;
             }
         }
@@ -326,7 +325,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         const float4 v = *reinterpret_cast<const float4*>(&s_out[line * CV_OUT_STRIDE + 4 * q4]);
         *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
     }
-    if (out_amax) ac_amax_commit(vmax, out_amax + (size_t)b * n_blk + by);
+    if (out_amax) {
+        ac_amax_commit(vmax[0], out_amax + (size_t)b * H + y0 + 2 * wave);
+        ac_amax_commit(vmax[1], out_amax + (size_t)b * H + y0 + 2 * wave + 1);
+    }
 }
 
 static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,

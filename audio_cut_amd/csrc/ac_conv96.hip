@@ -64,9 +64,8 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * C_in * plane;
     float act_inv;
-    // time-local power-of-two activation scale (ac_common.h): the patch covers rows y0 - 1 .. y0 + 8 = row blocks by - 1 .. by + 1
-    const int n_blk = H / AC_AMAX_ROWS, by = y0 / AC_AMAX_ROWS;
-    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * n_blk : nullptr, by > 0 ? by - 1 : 0, by + 1 < n_blk ? by + 1 : n_blk - 1,
+    // time-local power-of-two activation scale (ac_common.h): the maximum over exactly the patch rows y0 - 1 .. y0 + 8
+    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * H : nullptr, y0 > 0 ? y0 - 1 : 0, y0 + W9_TH < H ? y0 + W9_TH : H - 1,
                                      1.f, 0.f, &act_inv);
     const float unscale = w_unscale * act_inv;
 
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
         }
     }
     // ---- epilogue in passes of EP_M row tiles through the LDS tile [co][row][x] -> 128-byte row stores
-    float vmax = 0.f;
+    float vmax[2] = {0.f, 0.f};          // this wave's two output rows (ty = 2 wave + (q >> 1))
 #pragma unroll
     for (int m0 = 0; m0 < W9_MT; m0 += EP_M) {
         const int n_m = (W9_MT - m0) < EP_M ? (W9_MT - m0) : EP_M;
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
                         const int co = mm * 16 + g * 4 + r;
                         float v = acc[m][q][r] * unscale + bias[cob * W9_COB + m0 * 16 + co];
                         if (RELU) v = fmaxf(v, 0.f);
-                        vmax = fmaxf(vmax, fabsf(v));
+                        vmax[q >> 1] = fmaxf(vmax[q >> 1], fabsf(v));
                         s_out[(co * W9_TH + ty) * W9_OUT_STRIDE + tx] = v;
                     }
                 }
@@ -225,7 +224,10 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
             *reinterpret_cast<float4*>(ob + (size_t)co * plane + (size_t)(y0 + ty) * W + x0 + 4 * q4) = v;
         }
     }
-    if (out_amax) ac_amax_commit(vmax, out_amax + (size_t)b * n_blk + by);
+    if (out_amax) {
+        ac_amax_commit(vmax[0], out_amax + (size_t)b * H + y0 + 2 * wave);
+        ac_amax_commit(vmax[1], out_amax + (size_t)b * H + y0 + 2 * wave + 1);
+    }
 }
 
 static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,

@@ -61,14 +61,22 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     const int n0 = nb * BN;
     const int n_stage = K / GM_BK;
     // tile -> (item, group of 16 channels, block of 8 time rows); time blocks of one channel group are neighbours in the walk
-    const int n_blk = T / AC_AMAX_ROWS, n_cg = C / 16;
+    const int n_blk = T / 8, n_cg = C / 16;
     const int tb = mb % n_blk, cg = (mb / n_blk) % n_cg, item = mb / (n_blk * n_cg);
-    const size_t m_base = ((size_t)item * C + (size_t)cg * 16) * T + (size_t)tb * AC_AMAX_ROWS;      // global row of tile row 0
+    const size_t m_base = ((size_t)item * C + (size_t)cg * 16) * T + (size_t)tb * 8;                 // global row of tile row 0
     auto grow = [&](int r) -> size_t { return m_base + (size_t)(r >> 3) * T + (r & 7); };            // global row of tile row r
-    // time-local power-of-two activation scale (ac_common.h): the tile reads one row block of one item
-    float act_inv;
-    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)item * n_blk : nullptr, tb, tb, 1.f, 0.f, &act_inv);
-    const float unscale = w_unscale * act_inv;
+    // time-local power-of-two activation scale (ac_common.h): GEMM rows are independent, so every tile row is scaled by the
+    // maximum of its OWN time row (tile row r is time row tb * 8 + (r & 7)); the eight scale / inverse pairs and the eight
+    // output maxima of the tile live in LDS
+    __shared__ float s_scale[8], s_inv[8];
+    __shared__ unsigned s_tmax[8];
+    if (tid < 8) {
+        float inv;
+        s_scale[tid] = ac_act_scale_lane(in_amax ? in_amax + (size_t)item * T : nullptr, tb * 8 + tid, tb * 8 + tid, &inv);
+        s_inv[tid] = inv;
+        s_tmax[tid] = 0u;
+    }
+    __syncthreads();
 
     f32x4 acc[GM_MT][NT];
 #pragma unroll
@@ -79,12 +87,14 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     // staging coordinates: float4 e covers row e >> 3, k-quad e & 7 (8 lanes = one 128-byte row segment)
     const float* a_ptr[GM_A_ITERS];
     int a_off[GM_A_ITERS];
+    float a_scale[GM_A_ITERS];
 #pragma unroll
     for (int i = 0; i < GM_A_ITERS; ++i) {
         const int e = tid + 256 * i;
         const int row = e >> 3, kq = e & 7;
         a_ptr[i] = x + grow(row) * (size_t)K + 4 * kq;
         a_off[i] = row * GM_ASTRIDE + 4 * kq;
+        a_scale[i] = s_scale[row & 7];
     }
     const f16x8* wbase = wpk + (size_t)nb * n_stage * BFRAGS;
 
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
             unsigned short h[4], l[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float c = fminf(fmaxf(v[q] * act_s, -65504.f), 65504.f);
+                const float c = fminf(fmaxf(v[q] * a_scale[i], -65504.f), 65504.f);
                 const _Float16 hv = (_Float16)c;
                 h[q] = gm_f16_bits(hv);
                 l[q] = gm_f16_bits((_Float16)(c - (float)hv));
@@ -161,7 +171,6 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
         for (int i = 0; i < E_ITERS; ++i) { int c; rr[0][i] = *reinterpret_cast<const float4*>(resid + out_offset(0, i, c)); }
     }
     __syncthreads();                     // every wave is done reading the stage buffers
-    float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < GM_MT; ++m) {
 #pragma unroll
@@ -179,24 +188,28 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
             const int row = e / ROW_F4, q4 = e - row * ROW_F4;
             int c;
             const size_t o = out_offset(m, i, c);
-            const float sc = scale[c] * unscale, sh = shift[c];
+            const int tr = wm * 64 + m * 16 + row;
+            const float sc = scale[c] * (w_unscale * s_inv[tr & 7]), sh = shift[c];
             float4 v = *reinterpret_cast<const float4*>(&so[row * OSTRIDE + 4 * q4]);
             v.x = fmaxf(v.x * sc + sh, 0.f); v.y = fmaxf(v.y * sc + sh, 0.f);
             v.z = fmaxf(v.z * sc + sh, 0.f); v.w = fmaxf(v.w * sc + sh, 0.f);
             if (RESID) { const float4 q = rr[m & 1][i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            if (out_amax) atomicMax(&s_tmax[tr & 7], __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
             *reinterpret_cast<float4*>(y + o) = v;
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (out_amax) ac_amax_commit(vmax, out_amax + (size_t)item * n_blk + tb);
+    if (out_amax) {                      // max |y| per time row of the tile
+        __syncthreads();
+        if (tid < 8 && s_tmax[tid]) atomicMax(reinterpret_cast<unsigned*>(out_amax + (size_t)item * T + tb * 8 + tid), s_tmax[tid]);
+    }
 }
 
 extern "C" int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
                                     const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale,
                                     const float* in_amax, float* out_amax, void* stream) {
     AC_REQUIRE(ctx && x && w_packed && scale && shift && y, "null pointer");
-    AC_REQUIRE(M > 0 && C > 0 && T > 0 && C % 16 == 0 && T % AC_AMAX_ROWS == 0 && M % ((long long)C * T) == 0,
+    AC_REQUIRE(M > 0 && C > 0 && T > 0 && C % 16 == 0 && T % 8 == 0 && M % ((long long)C * T) == 0,
                "rows = items x C x T with C % 16 == 0 and T % 8 == 0 (a tile is 16 channels x 8 time rows)");
     AC_REQUIRE(K > 0 && K % GM_BK == 0, "K % 32 == 0");
     AC_REQUIRE(N > 0 && N % 96 == 0, "N % 96 == 0");

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void k_mdx_stft(const float* __restrict__ trac
         out[3 * cstride + k] = im;         // R.im
         vmax = fmaxf(vmax, fmaxf(fabsf(re), fabsf(im)));
     }
-    // max |spectrogram| per (item, block of 8 frames): the first conv's time-local activation scale (ac_common.h)
-    if (spec_amax) ac_amax_commit(vmax, spec_amax + (size_t)item * (MDX_T / AC_AMAX_ROWS) + t / AC_AMAX_ROWS);
+    // max |spectrogram| per (item, frame): the first conv's time-local activation scale (ac_common.h)
+    if (spec_amax) ac_amax_commit(vmax, spec_amax + (size_t)item * MDX_T + t);
 }
 
 extern "C" int ac_mdx_stft(ac_ctx* ctx, const float* track, int64_t n, const int64_t* chunk_start, const int64_t* chunk_len,

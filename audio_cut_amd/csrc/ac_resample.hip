@@ -71,12 +71,13 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     const int p0 = (mb - b * tiles_per_img) * RS_BM;                         // first pixel of the tile inside its image
     const size_t plane_in = (size_t)H * W;
     const float* xb = x + (size_t)b * Ci * plane_in;
-    // time-local power-of-two activation scale (ac_common.h): the tile's 128 pixels cover input rows r0 .. r1
-    const int nb_in = H / AC_AMAX_ROWS, nb_out = (MODE ? 2 * H : (H >> 1)) / AC_AMAX_ROWS;
-    const int r0 = MODE ? p0 / W : 2 * (p0 / Wo), r1 = MODE ? (p0 + RS_BM - 1) / W : 2 * ((p0 + RS_BM - 1) / Wo) + 1;
-    float act_inv;
-    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * nb_in : nullptr, r0 / AC_AMAX_ROWS, r1 / AC_AMAX_ROWS, 1.f, 0.f, &act_inv);
-    const float unscale = w_unscale * act_inv;
+    // time-local power-of-two activation scale (ac_common.h): GEMM rows (pixels) are independent, so each is scaled by the
+    // maximum of the input rows IT reads: its own row (up), rows 2 yo and 2 yo + 1 (down).  pix_scale(pixel of the M axis).
+    const float* amax_in = in_amax ? in_amax + (size_t)b * H : nullptr;
+    auto pix_scale = [&](int pix, float* inv) -> float {
+        const int r = MODE ? pix / W : 2 * (pix / Wo);
+        return ac_act_scale_lane(amax_in, r, MODE ? r : r + 1, inv);
+    };
 
     f32x4 acc[RS_MT][RS_NT];
 #pragma unroll
@@ -104,6 +105,8 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
         }
     }
     const int up_c4 = tid >> 5, up_q = tid & 31;
+    float ld_inv;
+    const float act_s = pix_scale(p0 + (MODE ? 4 * up_q : 2 * (tid & 63)), &ld_inv);      // the pixels this thread stages share one row (W, Wo even / % 4)
     const f16x8* wbase = wpk + (size_t)nb * n_stage * RS_BFRAGS;
 
     auto prefetch = [&](int s) {
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
     // ---- epilogues: D[row m = (lane >> 4) * 4 + r][col n = lane & 15]; strips are wave-private (LDS is in-order per wave)
     const int g = lane >> 4, px = lane & 15;
     __syncthreads();                     // every wave is done reading the stage buffers
-    float* amax_slots = out_amax ? out_amax + (size_t)b * nb_out : nullptr;
+    float* amax_slots = out_amax ? out_amax + (size_t)b * (MODE ? 2 * H : (H >> 1)) : nullptr;
     if (MODE == 0) {
         // down: NCHW output, pixels contiguous per channel.  Per n-tile: strip [16 n][64 m] -> 256-byte runs per channel.
         float* so = s_out + wave * 16 * OSTRIDE_DN;
@@ -198,6 +201,9 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 const int co = nb * RS_BN + wn * 48 + n * 16 + nn;
                 if (co < Co) {
                     const float bv = bias[co];
+                    float inv4;
+                    (void)pix_scale(p0 + wm * 64 + 4 * q4, &inv4);
+                    const float unscale = w_unscale * inv4;
                     float4 v = *reinterpret_cast<const float4*>(&so[nn * OSTRIDE_DN + 4 * q4]);
                     v.x = fmaxf(v.x * unscale + bv, 0.f); v.y = fmaxf(v.y * unscale + bv, 0.f);
                     v.z = fmaxf(v.z * unscale + bv, 0.f); v.w = fmaxf(v.w * unscale + bv, 0.f);
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
             __builtin_amdgcn_wave_barrier();
         }
         // every float4 of this lane = output pixels p0 + wm * 64 + 4 (lane & 15) .. + 3 of one output row (Wo % 4 == 0)
-        if (amax_slots) ac_amax_commit_blocks(vmax, ((p0 + wm * 64 + 4 * (lane & 15)) / Wo) / AC_AMAX_ROWS, amax_slots);
+        if (amax_slots) ac_amax_commit_blocks(vmax, (p0 + wm * 64 + 4 * (lane & 15)) / Wo, amax_slots);
     } else {
         // up: column n = co * 4 + dy * 2 + dx.  Per m-tile: strip [16 m][48 n]; one float4 = 2 input pixels x (dx 0, 1) of one
         // (co, dy): 8 consecutive lanes write a 128-byte run of an output row.  The skip rows are fetched one strip ahead.
@@ -241,13 +247,17 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 for (int i = 0; i < 3; ++i) { int nn; sk[(m + 1) & 1][i] = *reinterpret_cast<const float4*>(skip + out_offset(m + 1, i, nn)); }
             }
             __builtin_amdgcn_wave_barrier();
-            float vmax = 0.f;
+            float vmax[2] = {0.f, 0.f};          // output rows 2 yy (dy = 0) and 2 yy + 1 of this lane's input pixel pair
+            float inv2;
+            (void)pix_scale(p0 + wm * 64 + m * 16 + 2 * (lane & 7), &inv2);
+            const float unscale = w_unscale * inv2;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 int nn;
                 const size_t o = out_offset(m, i, nn);
                 const int mp = (lane + 64 * i) & 7;
                 const int co = (nb * RS_BN + wn * 48 + nn) >> 2;
+                const int dy = ((nb * RS_BN + wn * 48 + nn) >> 1) & 1;
                 const float bv = bias[co];
                 const float2 a0 = *reinterpret_cast<const float2*>(&so[(2 * mp) * OSTRIDE_UP + nn]);       // pixel 2mp:   dx 0, 1
                 const float2 a1 = *reinterpret_cast<const float2*>(&so[(2 * mp + 1) * OSTRIDE_UP + nn]);   // pixel 2mp+1: dx 0, 1
@@ -255,10 +265,13 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                                        fmaxf(a1.x * unscale + bv, 0.f), fmaxf(a1.y * unscale + bv, 0.f));
                 if (skip) { const float4 q = sk[m & 1][i]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
                 *reinterpret_cast<float4*>(out + o) = v;
-                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                vmax[dy] = fmaxf(fmaxf(vmax[dy], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
-            // the lane's three float4 of this strip are output rows 2 yy + {0, 1} of input pixel pair (lane & 7): one 8-row block
-            if (amax_slots) ac_amax_commit_blocks(vmax, (2 * ((p0 + wm * 64 + m * 16 + 2 * (lane & 7)) / W)) / AC_AMAX_ROWS, amax_slots);
+            if (amax_slots) {
+                const int yy2 = 2 * ((p0 + wm * 64 + m * 16 + 2 * (lane & 7)) / W);
+                ac_amax_commit_blocks(vmax[0], yy2, amax_slots);
+                ac_amax_commit_blocks(vmax[1], yy2 + 1, amax_slots);
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -278,6 +291,7 @@ static int rs_launch(int mode, ac_ctx* ctx, const float* x, const void* w_packed
         P = (long long)H * W; K = Ci; N = 4 * Co;
     }
     AC_REQUIRE(P % RS_BM == 0, "pixels per image % 128 == 0");
+    AC_REQUIRE(mode != 0 || !(in_amax || out_amax) || (W / 2) % 4 == 0, "down with amax: (W / 2) % 4 == 0 (a float4 of outputs stays in one row)");
     AC_REQUIRE((long long)H * W * 4 < (1LL << 31), "plane too large");
     const int n_stage = (K + RS_BK - 1) / RS_BK, n_nblk = (N + RS_BN - 1) / RS_BN;
     const long long n_mblk = (long long)B * (P / RS_BM);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_tdf_small(const float* __restrict__ x, 
             const int c = (int)(((m0 + row) / T) % C);
             sc2[mt][i] = s2[c]; sf2[mt][i] = b2[c];
         }
-    float vmax[2] = {0.f, 0.f};                              // per 16-row tile: this lane's rows 4 g .. 4 g + 3 lie in one 8-row block
+    float vmax[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // per output row of this lane (rows mt * 16 + 4 g + i)
     const int n_nt2 = F / 16;
     for (int nt = 0; nt < n_nt2; ++nt) {
         f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -117,16 +117,22 @@ __global__ __launch_bounds__(256) void k_tdf_small(const float* __restrict__ x, 
             for (int i = 0; i < 4; ++i) {
                 const size_t o = (size_t)(m0 + crow[mt][i]) * F + nt * 16 + r;
                 const float v = x[o] + fmaxf(acc[mt][i] * sc2[mt][i] + sf2[mt][i], 0.f);
-                vmax[mt] = fmaxf(vmax[mt], fabsf(v));
+                vmax[mt][i] = fmaxf(vmax[mt][i], fabsf(v));
                 y[o] = v;
             }
     }
-    if (out_amax) {          // max |y| per (item, block of 8 time rows): lanes 0-31 hold rows 0-7 of a tile, lanes 32-63 rows 8-15
-        const int n_blk = T / AC_AMAX_ROWS;
-        float* slots = out_amax + (m0 / ((long long)C * T)) * n_blk;
+    if (out_amax) {          // max |y| per (item, time row): a row's 16 columns sit in the 16 lanes of one lane group
+        float* slots = out_amax + (m0 / ((long long)C * T)) * T;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-            ac_amax_commit_halves(vmax[mt], slots + (int)((m0 + mt * 16 + 8 * (g >> 1)) % T) / AC_AMAX_ROWS);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = vmax[mt][i];
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, AC_WAVE));
+                if (r == 0 && v > 0.f)
+                    atomicMax(reinterpret_cast<unsigned*>(slots + (int)((m0 + mt * 16 + 4 * g + i) % T)), __float_as_uint(v));
+            }
     }
 }
 
@@ -138,7 +144,7 @@ extern "C" int ac_tdf_small_fused(ac_ctx* ctx, const float* x, const void* w1_pa
     AC_REQUIRE(F > 0 && F % 16 == 0, "F % 16 == 0");
     AC_REQUIRE(Hd > 0 && Hd <= TS_HMAX, "bottleneck width in [1, 48]");
     AC_REQUIRE(T > 0 && C > 0, "T, C > 0");
-    AC_REQUIRE(!out_amax || (((long long)C * T) % TS_ROWS == 0 && T % AC_AMAX_ROWS == 0), "amax needs (C * T) % 32 == 0 and T % 8 == 0");
+    AC_REQUIRE(!out_amax || ((long long)C * T) % TS_ROWS == 0, "amax needs (C * T) % 32 == 0 (a wave's 32 rows inside one item)");
     AC_REQUIRE(x != y, "in-place not supported (the residual is re-read)");
     const long long n_wave = M / TS_ROWS;
     const long long nblk = (n_wave + 3) / 4;

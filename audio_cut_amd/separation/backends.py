@@ -219,7 +219,7 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             b = min(n_items, a + step)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timings is not None else None
             if ev: ev[0].record()
-            amax = torch.zeros((b - a, 32), dtype=torch.float32, device=hip.device)   # max |spec| per item and 8 frames: the first conv's activation scale
+            amax = torch.zeros((b - a, 256), dtype=torch.float32, device=hip.device)  # max |spec| per item and frame: the first conv's activation scale
             spec = hip.mdx_stft(track_dev, d_cs[a:b].contiguous(), d_cl[a:b].contiguous(), d_wi[a:b].contiguous(), amax=amax)
             if ev: ev[1].record()
             out = net.forward_tf(spec, amax)

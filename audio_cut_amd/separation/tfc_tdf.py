@@ -99,13 +99,13 @@ def _fold(weight: np.ndarray, bias: Optional[np.ndarray], w: Weights, bn_name: s
     return wf.astype(np.float32), bf.astype(np.float32)
 
 
-AMAX_ROWS = 8       # AC_AMAX_ROWS (csrc/ac_common.h): rows of the time axis per amax block
+AMAX_ROWS = 1       # AC_AMAX_ROWS (csrc/ac_common.h): one activation maximum per item and row of the time axis
 
 
 class _AmaxTape:
-    """Per-forward scratch of activation maxima (include/audiocut_hip.h, "amax"): one zeroed float32 [B, T / 8] array per tensor
-    that a split-float16 kernel will read; the producing kernel reduces max |x| per item and block of 8 time rows into it, the
-    consumer derives its time-local power-of-two activation scale from the blocks its tile touches.  One allocation + one
+    """Per-forward scratch of activation maxima (include/audiocut_hip.h, "amax"): one zeroed float32 [B, T] array per tensor
+    that a split-float16 kernel will read; the producing kernel reduces max |x| per item and time row into it, the consumer
+    derives its time-local power-of-two activation scale from exactly the rows one accumulation reads.  One allocation + one
     memset per forward."""
 
     def __init__(self, batch: int, t_full: int, n_tensors: int, device: torch.device):
@@ -323,7 +323,7 @@ class TfcTdfNet(nn.Module):
         """T-major call `[B, 4, T, F]` -> `[B, 4, T, F]`: the graph transposes right after its first 1x1
         conv and right before its last one (1x1 convs commute with the transpose), so the HIP STFT writes
         and the HIP iSTFT reads this layout directly and no transpose is ever materialised.
-        `spec_amax` [B, T / 8] = max |spec| per item and block of 8 frames as ac_mdx_stft reduces it (computed here when absent)."""
+        `spec_amax` [B, T] = max |spec| per item and frame as ac_mdx_stft reduces it (computed here when absent)."""
         from .._native import NativeError
         hip = self.hip
         if hip is None or not spec_tf.is_cuda:

@@ -135,7 +135,7 @@ int ac_pause_cut_points(ac_ctx* ctx, const float* x, int64_t n, const int64_t* a
  * layout; channels L.re, L.im, R.re, R.im of the mono-duplicated input, backends.py:269-270). */
 int ac_mdx_stft(ac_ctx* ctx, const float* track, int64_t n, const int64_t* chunk_start,
                 const int64_t* chunk_len, const int32_t* win_index, int n_items, float* spec_out,
-                float* spec_amax /* [n_items][32], zeroed by the caller, may be NULL: max |spec| per item and block of 8 frames (see "amax" below) */,
+                float* spec_amax /* [n_items][256], zeroed by the caller, may be NULL: max |spec| per item and frame (see "amax" below) */,
                 void* stream);
 
 /* external Conv_TDF_net_trim_model.istft (backends.py:376): spec[n_items][4][256][3072] ->
@@ -170,14 +170,15 @@ int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int
  * ([C_out/48][C_in/16][5][hi,lo][3][64] fragments of 8 f16).  C_in % 16 == 0, C_out % 48 == 0, H % 8 == 0,
  * W % 32 == 0.  out = conv(x) * w_unscale + bias[c], followed by ReLU when relu != 0.
  *
- * "amax" (every split-float16 kernel below takes the pair): in_amax [B][H / 8] float32 = max |x| of each batch item and block
- * of 8 rows of the time axis H (H = T for the TDF kernels) of the INPUT tensor, as written by the kernel that produced it.  A
- * kernel takes the maximum over the blocks its tile touches and scales the activations by the power of two that puts it in
- * [2^14, 2^15) before the float16 split (undone exactly in the epilogue): the low part stays a normal float16 down to 2^-17 of
- * the LOCAL peak and the representation error is max(2^-22 |x|, 2^-40 local max) instead of max(2^-22 |x|, 3e-8) -
- * float32-class relative accuracy for quiet items, for decays into silence and for silent stretches between loud passages
- * (where the quiet guard decides), and no saturation at 65504.  out_amax [B][H_out / 8] (zeroed by the caller before the
- * launch) receives max |out| per item and row block by ordered-bits atomicMax.  H % 8 == 0 whenever either is given.
+ * "amax" (every split-float16 kernel below takes the pair): in_amax [B][H] float32 = max |x| of each batch item and row of the
+ * time axis H (H = T for the TDF kernels) of the INPUT tensor, as written by the kernel that produced it.  A kernel takes the
+ * maximum over exactly the rows that enter one accumulation (the 10 patch rows of a 3x3 conv tile; the single time row of a
+ * TDF GEMM row; the two input rows of a 2x2 down-sampling pixel, the one row of an up-sampling pixel) and scales the
+ * activations by the power of two that puts it in [2^14, 2^15) before the float16 split (undone exactly in the epilogue): the
+ * low part stays a normal float16 down to 2^-17 of the LOCAL peak and the representation error is
+ * max(2^-22 |x|, 2^-40 local max) instead of max(2^-22 |x|, 3e-8) - float32-class relative accuracy for quiet items, for
+ * decays into silence and for the leakage next to a loud passage (where the quiet guard decides), and no saturation at 65504.
+ * out_amax [B][H_out] (zeroed by the caller before the launch) receives max |out| per item and row by ordered-bits atomicMax.
  * Either may be NULL: no scaling (the pre-ABI-2 behaviour) / no reduction. */
 int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                      int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
@@ -198,13 +199,13 @@ int ac_conv1x1_small(ac_ctx* ctx, const float* x, const float* w, const float* b
  * 96 columns), K % 32 == 0, N % 96 == 0. */
 int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* scale, const float* shift,
                         const float* resid, float* y, long long M, int N, int K, int T, int C, float w_unscale,
-                        const float* in_amax, float* out_amax /* [M / (C*T)][T / 8] */, void* stream);
+                        const float* in_amax, float* out_amax /* [M / (C*T)][T] */, void* stream);
 
 /* Both TDF layers + residual of a block at the deep levels (F = 384 / 192 / 96, bottleneck Hd = F / 8 <= 48: too narrow for
  * ac_tdf_linear_f16x3), one kernel, exact float32 on v_mfma_f32_16x16x4_f32 (same graph nodes as ac_tdf_linear_f16x3):
  *   y[m][n] = x[m][n] + relu(scale2[c] * sum_j relu(scale1[c] * sum_f x[m][f] w1[j][f] + shift1[c]) w2[n][j] + shift2[c])
- * w1_packed / w2_packed from conv_pack.pack_tdf_small.  M % 32 == 0, F % 16 == 0, x != y.  out_amax [M / (C*T)][T / 8] as above
- * (needs (C * T) % 32 == 0, T % 8 == 0); no in_amax: nothing is split. */
+ * w1_packed / w2_packed from conv_pack.pack_tdf_small.  M % 32 == 0, F % 16 == 0, x != y.  out_amax [M / (C*T)][T] as above
+ * (needs (C * T) % 32 == 0); no in_amax: nothing is split. */
 int ac_tdf_small_fused(ac_ctx* ctx, const float* x, const void* w1_packed, const void* w2_packed, const float* scale1,
                        const float* shift1, const float* scale2, const float* shift2, float* y, long long M, int F, int Hd,
                        int T, int C, float* out_amax, void* stream);
@@ -293,7 +294,7 @@ int ac_pack_pcm24(ac_ctx* ctx, const float* x, int64_t n, unsigned char* out, vo
 /* ac_conv3x3_f16x3 with the graph's first 1x1 convolution (spec [B][C0][H][W], C0 <= 4, w1 [C_in][C0], b1 [C_in], + ReLU;
  * the first Conv + BatchNormalization + Relu nodes at separation/backends.py:358) fused into its loader: the C_in-channel
  * tensor is generated per staged pixel with ac_conv1x1_small's arithmetic (bit-identical) and never written to HBM.
- * spec_amax [B][H / 8] = max |spec| per item and row block (ac_mdx_stft); the generated tensor's maximum is bounded by
+ * spec_amax [B][H] = max |spec| per item and row (ac_mdx_stft); the generated tensor's maximum is bounded by
  * spec_amax * amax_gain + amax_offs with amax_gain = max_c sum_j |w1[c][j]|, amax_offs = max_c |b1[c]| (host constants). */
 int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,
                            const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W, float w_unscale,

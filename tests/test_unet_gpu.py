@@ -209,7 +209,7 @@ def test_first_conv_fused_into_the_3x3_loader_is_bit_identical(hip_ctx):
     # measured maximum - the same values up to the float16 low parts' last bit
     amax_spec = _blk_amax(spec)
     gain = float(w1.abs().sum(dim=(1, 2, 3)).max()); offs = float(b1.abs().max())
-    oa = torch.zeros((2, 2), device=dev)
+    oa = torch.zeros((2, 16), device=dev)
     got2 = hip_ctx.conv3x3_f16x3_first(spec, w1, b1, wp, b3, 48, un, relu=True, spec_amax=amax_spec, amax_gain=gain, amax_offs=offs, out_amax=oa)
     assert bool((_blk_amax(mid) <= amax_spec * gain + offs).all())
     ref2 = hip_ctx.conv3x3_f16x3(mid, wp, b3, 48, un, relu=True, in_amax=_blk_amax(mid))
@@ -218,9 +218,8 @@ def test_first_conv_fused_into_the_3x3_loader_is_bit_identical(hip_ctx):
 
 
 def _blk_amax(t: torch.Tensor) -> torch.Tensor:
-    """max |t| per item and block of 8 rows of the time axis (dim 2): the "amax" tensors of include/audiocut_hip.h."""
-    b, _, h, _ = t.shape
-    return t.abs().amax(dim=(1, 3)).view(b, h // 8, 8).amax(dim=2).contiguous()
+    """max |t| per item and row of the time axis (dim 2): the "amax" tensors of include/audiocut_hip.h."""
+    return t.abs().amax(dim=(1, 3)).contiguous()
 
 
 def _elementwise_error(y: torch.Tensor, ref64: torch.Tensor, scale64: torch.Tensor) -> float:
@@ -232,7 +231,7 @@ def _elementwise_error(y: torch.Tensor, ref64: torch.Tensor, scale64: torch.Tens
 def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
     """The per-item activation scale (include/audiocut_hip.h, "amax"): every split-float16 kernel is fed inputs from 1e-6 to 1e6
     (past the float16 range: nothing saturates), uniform and with a 1e-8 decay along the time axis inside one item (the scale is
-    local in time: blocks of 8 rows), and its
+    local in time: the rows one accumulation reads), and its
     ELEMENT-WISE error against float64 must stay within 4x of what a true float32 evaluation (PyTorch CPU float32) of the same
     layer delivers.  Without the scale the 1e-6 and decaying cases are 2-4 orders of magnitude worse (the low float16 part is
     a subnormal) and the 1e6 case clips.  out_amax must be the exact per-item maximum of the result."""
@@ -253,7 +252,7 @@ def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
                     xm = torch.cat([xm[:1], xm[1:] * ramp], dim=0)
                 ia = _blk_amax(xm).to(dev)
                 y = run(xm.to(dev), ia, None)
-                oa = torch.zeros((x.shape[0], y.shape[2] // 8), device=dev)
+                oa = torch.zeros((x.shape[0], y.shape[2]), device=dev)
                 assert torch.equal(run(xm.to(dev), ia, oa), y) and torch.equal(oa, _blk_amax(y)), (name, mag)
                 ref64, scale64 = ref_fn(xm.double(), torch.float64)
                 y32, _ = ref_fn(xm, torch.float32)
@@ -338,7 +337,7 @@ def test_tdf_small_fused_kernel(hip_ctx):
         s1 = torch.rand(c, generator=g) + 0.5; b1 = torch.randn(c, generator=g) * 0.3
         s2 = torch.rand(c, generator=g) + 0.5; b2 = torch.randn(c, generator=g) * 0.3
         p1, p2 = pack_tdf_small(w1.numpy(), w2.numpy())
-        oa = torch.zeros((b, t // 8), device=dev)
+        oa = torch.zeros((b, t), device=dev)
         y = hip_ctx.tdf_small_fused(x.to(dev), torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev), hd, s1.to(dev), b1.to(dev),
                                     s2.to(dev), b2.to(dev), out_amax=oa)
         v = lambda a: a.double().view(1, -1, 1, 1)
