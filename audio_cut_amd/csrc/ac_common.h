@@ -88,7 +88,7 @@ __device__ inline float ac_act_scale(const float* __restrict__ amax_item, int b0
             int e;
             (void)frexpf(a, &e);                    // a = m * 2^e, m in [0.5, 1)
             e = 15 - e;
-            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            e = e < -120 ? -120 : (e > 120 ? 120 : e);
             s = ldexpf(1.f, e);
             *inv = ldexpf(1.f, -e);
         }
@@ -97,6 +97,42 @@ __device__ inline float ac_act_scale(const float* __restrict__ amax_item, int b0
     *inv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(*inv)));
     s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
     return s;
+}
+// The 3x3 conv kernels stage ONE patch (10 rows) for the eight output rows of a tile.  Where the maxima of those rows lie within
+// 2^AC_ROWX_SPREAD of each other (music: practically always) one common scale serves every output row with a floor of
+// 2^-40 * 2^SPREAD = 2^-28 of the quietest row - below float32's own 2^-24.  Where they do not (the leakage of a burst decaying by
+// decades per frame into digital silence) the tile takes the row-exact path: every patch row is staged with its OWN scale
+// s_r = 2^ex_r, output row y accumulates at the scale of the loudest of ITS three input rows, S_y = 2^min(ex_y-1, ex_y, ex_y+1),
+// and an activation fragment of row r is multiplied by the exact power of two S_y / s_r <= 1 (v_pk_mul_f16) on its way into the
+// MFMA (factors below 2^-24, the smallest float16, are contributions below float32's resolution and become 0).
+#define AC_EX_NONE 0x7fffffff
+#define AC_ROWX_SPREAD 12
+// log2 of the power-of-two scale of a row whose maximum is a (the scale puts a in [2^14, 2^15)); AC_EX_NONE: no usable maximum
+__device__ inline int ac_row_ex(float a) {
+    if (!(a > 0.f && a < 3.0e38f)) return AC_EX_NONE;
+    int e;
+    (void)frexpf(a, &e);
+    e = 15 - e;
+    return e < -120 ? -120 : (e > 120 ? 120 : e);
+}
+// factor that takes a fragment staged at 2^ex_row to the output row's scale 2^ex_out (ex_out <= ex_row)
+__device__ inline float ac_rowx_factor(int ex_row, int ex_out) {
+    if (ex_row == AC_EX_NONE || ex_out == AC_EX_NONE) return 1.f;      // an all-zero row: its values are zeros at any scale
+    const int d = ex_row - ex_out;
+    return d <= 24 ? ldexpf(1.f, -d) : 0.f;
+}
+// s_ex[r] = log2 scale of patch row r (LDS); output row ty reads patch rows ty, ty + 1, ty + 2.  AC_EX_NONE is the largest int,
+// so the minimum skips empty rows.  Computed where they are used: the common path must not carry registers for this one.
+__device__ inline int ac_rowx_out_ex(const int* s_ex, int ty) {
+    int e = s_ex[ty] < s_ex[ty + 1] ? s_ex[ty] : s_ex[ty + 1];
+    return e < s_ex[ty + 2] ? e : s_ex[ty + 2];
+}
+__device__ inline _Float16 ac_rowx_frag_factor(const int* s_ex, int ty, int dy) {
+    return (_Float16)ac_rowx_factor(s_ex[ty + dy], ac_rowx_out_ex(s_ex, ty));
+}
+__device__ inline float ac_rowx_unscale(const int* s_ex, int ty) {
+    const int e = ac_rowx_out_ex(s_ex, ty);
+    return e == AC_EX_NONE ? 1.f : ldexpf(1.f, -e);
 }
 // the same for arguments that differ from lane to lane (a GEMM row's own time row)
 __device__ inline float ac_act_scale_lane(const float* __restrict__ amax_item, int b0, int b1, float* inv) {
@@ -109,7 +145,7 @@ __device__ inline float ac_act_scale_lane(const float* __restrict__ amax_item, i
             int e;
             (void)frexpf(a, &e);
             e = 15 - e;
-            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            e = e < -120 ? -120 : (e > 120 ? 120 : e);
             s = ldexpf(1.f, e);
             *inv = ldexpf(1.f, -e);
         }

@@ -94,12 +94,27 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     const int n_cb = C_in / CV_CB;
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * (FIRST ? C0 : C_in) * plane;
-    // time-local power-of-two activation scale (ac_common.h).  FIRST: in_amax is max|spectrogram|; the tensor that is split is the
-    // generated relu(w1 x + b1), bounded by amax * max_c sum_j |w1[c][j]| + max_c |b1[c]| (amax_gain, amax_offs from the host)
-    float act_inv;
-    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * H : nullptr, y0 > 0 ? y0 - 1 : 0, y0 + CV_TH < H ? y0 + CV_TH : H - 1,
-                                     amax_gain, amax_offs, &act_inv);          // exactly the patch rows y0 - 1 .. y0 + 8
-    const float unscale = w_unscale * act_inv;
+    // time-local power-of-two activation scale (ac_common.h): log2 scale of each patch row y0 - 1 .. y0 + 8.  FIRST: in_amax is
+    // max|spectrogram| per row; the tensor that is split is the generated relu(w1 x + b1), bounded per row by
+    // amax * max_c sum_j |w1[c][j]| + max_c |b1[c]| (amax_gain, amax_offs from the host)
+    __shared__ int s_ex[CV_PH + 2];
+    if (tid < CV_PH + 2) {
+        const int gy = y0 - 1 + tid;
+        s_ex[tid] = (in_amax && tid < CV_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy] * amax_gain + amax_offs) : AC_EX_NONE;
+    }
+    __syncthreads();
+    int ex_min = AC_EX_NONE, ex_max = -AC_EX_NONE;
+#pragma unroll
+    for (int r = 0; r < CV_PH; ++r) {
+        const int e = s_ex[r];
+        if (e != AC_EX_NONE) { ex_min = e < ex_min ? e : ex_min; ex_max = e > ex_max ? e : ex_max; }
+    }
+    ex_min = __builtin_amdgcn_readfirstlane(ex_min);
+    ex_max = __builtin_amdgcn_readfirstlane(ex_max);
+    // one scale for the tile where its rows are within 2^AC_ROWX_SPREAD of each other, else the row-exact path (ac_common.h)
+    const bool rowx = ex_min != AC_EX_NONE && ex_max - ex_min > AC_ROWX_SPREAD;
+    const float act_s = ex_min == AC_EX_NONE ? 1.f : ldexpf(1.f, ex_min);
+    const float unscale = w_unscale * (ex_min == AC_EX_NONE ? 1.f : ldexpf(1.f, -ex_min));
 
     f32x4 acc[CV_MT][4];
 #pragma unroll
@@ -205,6 +220,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
             if (a_c4[i] < 0) continue;
             const float* v4[4] = {&pre_x[i][0].x, &pre_x[i][1].x, &pre_x[i][2].x, &pre_x[i][3].x};
+            float a_s = act_s;
+            if (rowx) {                                                // row-exact path: the item's own patch row's scale
+                const int e = s_ex[a_off[i] / (CV_LW * CV_PIX_STRIDE)];
+                a_s = e == AC_EX_NONE ? 1.f : ldexpf(1.f, e);
+            }
             float gen[4][4];                                           // FIRST: [virtual channel q][pixel k]
             if (FIRST) {
 #pragma unroll
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fminf(fmaxf((FIRST ? gen[q][k] : v4[q][k]) * act_s, -65504.f), 65504.f);
+                    const float v = fminf(fmaxf((FIRST ? gen[q][k] : v4[q][k]) * a_s, -65504.f), 65504.f);
                     const _Float16 hv = (_Float16)v;                   // v_cvt_f16_f32, round to nearest even
                     h4[q] = f16_bits(hv);
                     l4[q] = f16_bits((_Float16)(v - (float)hv));
@@ -254,8 +274,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
             for (int q = 0; q < 4; ++q) {
                 const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
                 const int off = ((ty + dy) * CV_LW + cv_phys(tx + dx + 3)) * CV_PIX_STRIDE + ci_off;   // patch column c is staged column c + 3
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(&s_hi[off]);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+                f16x8 bh = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+                f16x8 bl = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+                if (rowx) { const _Float16 f = ac_rowx_frag_factor(s_ex, ty, dy); bh *= (f16x8)f; bl *= (f16x8)f; }
 #pragma unroll
                 for (int m = 0; m < CV_MT; ++m) {
                     acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][q], 0, 0, 0);
@@ -273,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                 const int off = ((ty + 2) * CV_LW + cv_phys(tx + 2 + 3)) * CV_PIX_STRIDE + ci_off;
                 k8h[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
                 k8l[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+                if (rowx) { const _Float16 f = ac_rowx_frag_factor(s_ex, ty, 2); k8h[q] *= (f16x8)f; k8l[q] *= (f16x8)f; }
             }
         }
         if (shared_step) {
@@ -306,10 +328,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+            const float us = rowx ? w_unscale * ac_rowx_unscale(s_ex, ty) : unscale;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = m * 16 + g * 4 + r;
-                float v = acc[m][q][r] * unscale + bias[cob * CV_COB + co];
+                float v = acc[m][q][r] * us + bias[cob * CV_COB + co];
                 if (RELU) v = fmaxf(v, 0.f);
                 vmax[q >> 1] = fmaxf(vmax[q >> 1], fabsf(v));
                 s_out[(co * CV_TH + ty) * CV_OUT_STRIDE + tx] = v;

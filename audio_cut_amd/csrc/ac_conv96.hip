@@ -32,42 +32,36 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
 // MT = 16-row output-channel tiles per workgroup: 6 (96 channels, two workgroups per CU) or 3 (48 channels, three per CU).
-template <int MT, int OCC, bool RELU>
-__global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __restrict__ x, const f16x8* __restrict__ wpk,
-                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                              int C_in, int C_out, int H, int W, float w_unscale, int bw,
-                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax) {
+// ROWX: the row-exact path of ac_common.h (per-row staging scales, power-of-two fragment factors); s_ex = log2 scale per patch row.
+template <int MT, bool RELU, bool ROWX>
+__device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8* __restrict__ wpk, const float* __restrict__ bias,
+                                        float* __restrict__ out, int C_in, int C_out, int H, int W, float w_unscale,
+                                        float* __restrict__ out_amax, unsigned char* s_raw, const int* s_ex, int ex_min,
+                                        int cob, int b, int y0, int x0) {
     constexpr int W9_MT = MT, W9_COB = 16 * MT;
     constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
     constexpr int EP_M = (MT == 6) ? 3 : 2;                   // row tiles per epilogue pass (the output tile must fit the arena)
-    constexpr int EP_BYTES = EP_M * 16 * W9_TH * W9_OUT_STRIDE * 4;
-    constexpr int K_BYTES = W9_PATCH_BYTES + (2 + 3) * W9_KFR * 16;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[K_BYTES > EP_BYTES ? K_BYTES : EP_BYTES];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + W9_PH * W9_RS * W9_CB;
     f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw + W9_PATCH_BYTES);           // even stages: 2 k-steps
     f16x8* s_w1 = s_w0 + 2 * W9_KFR;                                           // odd stages: 2 k-steps (+ the shared tap-8 step)
     float* s_out = reinterpret_cast<float*>(s_raw);                           // [16 EP_M co][8 rows][36], MT / EP_M passes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_cob = C_out / W9_COB;
-    const int tiles_x = W / W9_TW, tiles_y = H / W9_TH;
-    int wi = blockIdx.x;                                                       // XCD-aware order as in ac_conv.hip
-    if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int cob = wi % n_cob;
-    int t = wi / n_cob;
-    const int b = t / (tiles_x * tiles_y);
-    t -= b * (tiles_x * tiles_y);
-    const int band = t / (tiles_y * bw);
-    t -= band * (tiles_y * bw);
-    const int y0 = (t / bw) * W9_TH, x0 = (band * bw + t % bw) * W9_TW;
+    const int g = lane >> 4, px = lane & 15;
     const int n_cb = C_in / W9_CB;                                             // even: the stage that issues a shared step is always odd
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * C_in * plane;
-    float act_inv;
-    // time-local power-of-two activation scale (ac_common.h): the maximum over exactly the patch rows y0 - 1 .. y0 + 8
-    const float act_s = ac_act_scale(in_amax ? in_amax + (size_t)b * H : nullptr, y0 > 0 ? y0 - 1 : 0, y0 + W9_TH < H ? y0 + W9_TH : H - 1,
-                                     1.f, 0.f, &act_inv);
-    const float unscale = w_unscale * act_inv;
+    // staging: thread -> (row 0..9, column quad 0..9, channel quad 0..1): one aligned float4 (4 pixels) of 4 channels each
+    const int a_c4 = tid & 1, a_rest = tid >> 1;
+    const int a_row = a_rest / 10, a_qd = a_rest - a_row * 10;
+    const bool a_live = a_rest < W9_PH * 10;
+    // common path: one scale for the tile = the maximum over exactly the patch rows y0 - 1 .. y0 + 8 (ex_min is its log2)
+    float act_s = ex_min == AC_EX_NONE ? 1.f : ldexpf(1.f, ex_min);
+    if (ROWX) {                          // row-exact path: this thread stages one patch row, at that row's own scale
+        const int e_row = a_live ? s_ex[a_row] : AC_EX_NONE;
+        act_s = e_row == AC_EX_NONE ? 1.f : ldexpf(1.f, e_row);
+    }
+    const float unscale = w_unscale * (ex_min == AC_EX_NONE ? 1.f : ldexpf(1.f, -ex_min));
 
     f32x4 acc[W9_MT][4];
 #pragma unroll
@@ -78,14 +72,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) { k8h[q] = (f16x8)(_Float16)0; k8l[q] = (f16x8)(_Float16)0; }
 
-    const int g = lane >> 4, px = lane & 15;
     // fragments per stage in the packed weights: [cob][cb][3 k-steps][2][6][64]; the third k-step exists for cb & 3 == 3 only
     const f16x8* wbase = wpk + (size_t)cob * n_cb * 3 * W9_KFR;
 
-    // staging: thread -> (row 0..9, column quad 0..9, channel quad 0..1): one aligned float4 (4 pixels) of 4 channels each
-    const int a_c4 = tid & 1, a_rest = tid >> 1;
-    const int a_row = a_rest / 10, a_qd = a_rest - a_row * 10;
-    const bool a_live = a_rest < W9_PH * 10;
     int a_src = -1;
     const int a_off = ((a_row * W9_RS + 4 * a_qd) * W9_CB + a_c4 * 4);         // u16 elements
     if (a_live) {
@@ -154,6 +143,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
                 const int off = ((ty + dy) * W9_RS + tx + dx + 3) * W9_CB;           // patch column c is staged column c + 3
                 bh[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
                 bl[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+                if (ROWX) { const _Float16 f = ac_rowx_frag_factor(s_ex, ty, dy); bh[q] *= (f16x8)f; bl[q] *= (f16x8)f; }
             }
 #pragma unroll
             for (int m = 0; m < W9_MT; ++m) {
@@ -175,6 +165,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
                 const int off = ((ty + 2) * W9_RS + tx + 2 + 3) * W9_CB;
                 k8h[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
                 k8l[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+                if (ROWX) { const _Float16 f = ac_rowx_frag_factor(s_ex, ty, 2); k8h[q] *= (f16x8)f; k8l[q] *= (f16x8)f; }
             }
         }
         if ((cb & 3) == 3 || cb == n_cb - 1) {           // a trailing group of two stages: lane groups 2-3 meet zero weights
@@ -204,10 +195,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
+                    const float us = ROWX ? w_unscale * ac_rowx_unscale(s_ex, ty) : unscale;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int co = mm * 16 + g * 4 + r;
-                        float v = acc[m][q][r] * unscale + bias[cob * W9_COB + m0 * 16 + co];
+                        float v = acc[m][q][r] * us + bias[cob * W9_COB + m0 * 16 + co];
                         if (RELU) v = fmaxf(v, 0.f);
                         vmax[q >> 1] = fmaxf(vmax[q >> 1], fabsf(v));
                         s_out[(co * W9_TH + ty) * W9_OUT_STRIDE + tx] = v;
@@ -228,6 +220,48 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
         ac_amax_commit(vmax[0], out_amax + (size_t)b * H + y0 + 2 * wave);
         ac_amax_commit(vmax[1], out_amax + (size_t)b * H + y0 + 2 * wave + 1);
     }
+}
+
+template <int MT, int OCC, bool RELU>
+__global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __restrict__ x, const f16x8* __restrict__ wpk,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int C_in, int C_out, int H, int W, float w_unscale, int bw,
+                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax) {
+    constexpr int W9_COB = 16 * MT, W9_KFR = 2 * MT * 64, EP_M = (MT == 6) ? 3 : 2;
+    constexpr int EP_BYTES = EP_M * 16 * W9_TH * W9_OUT_STRIDE * 4;
+    constexpr int K_BYTES = W9_PATCH_BYTES + (2 + 3) * W9_KFR * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[K_BYTES > EP_BYTES ? K_BYTES : EP_BYTES];
+    __shared__ int s_ex[W9_PH + 2];
+    const int tid = threadIdx.x;
+    const int n_cob = C_out / W9_COB;
+    const int tiles_x = W / W9_TW, tiles_y = H / W9_TH;
+    int wi = blockIdx.x;                                                       // XCD-aware order as in ac_conv.hip
+    if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int cob = wi % n_cob;
+    int t = wi / n_cob;
+    const int b = t / (tiles_x * tiles_y);
+    t -= b * (tiles_x * tiles_y);
+    const int band = t / (tiles_y * bw);
+    t -= band * (tiles_y * bw);
+    const int y0 = (t / bw) * W9_TH, x0 = (band * bw + t % bw) * W9_TW;
+    // time-local power-of-two activation scale (ac_common.h): log2 scale of each patch row y0 - 1 .. y0 + 8
+    if (tid < W9_PH + 2) {
+        const int gy = y0 - 1 + tid;
+        s_ex[tid] = (in_amax && tid < W9_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy]) : AC_EX_NONE;
+    }
+    __syncthreads();
+    int ex_min = AC_EX_NONE, ex_max = -AC_EX_NONE;
+#pragma unroll
+    for (int r = 0; r < W9_PH; ++r) {
+        const int e = s_ex[r];
+        if (e != AC_EX_NONE) { ex_min = e < ex_min ? e : ex_min; ex_max = e > ex_max ? e : ex_max; }
+    }
+    ex_min = __builtin_amdgcn_readfirstlane(ex_min);
+    ex_max = __builtin_amdgcn_readfirstlane(ex_max);
+    if (ex_min != AC_EX_NONE && ex_max - ex_min > AC_ROWX_SPREAD)
+        w9_tile<MT, RELU, true>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0);
+    else
+        w9_tile<MT, RELU, false>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0);
 }
 
 static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,

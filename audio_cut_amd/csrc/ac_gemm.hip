@@ -7,8 +7,9 @@
 //
 // Workgroup: 256 threads = 2 x 2 waves, tile 128 rows x (32 * NT) columns, wave tile 64 x (16 * NT) (NT = 6 or 3).
 // The 128 rows of a tile are 16 channels x 8 consecutive time rows of one item (tile row r = channel r >> 3, time r & 7):
-// every row is its own contiguous F-vector, so the loads do not care, and a tile then lies in exactly ONE 8-row block of the
-// time axis - its activation scale is that block's maximum (ac_common.h), and it commits one output maximum.
+// every row is its own contiguous F-vector, so the loads do not care, and a tile then touches exactly 8 entries of the
+// per-time-row activation maxima (ac_common.h): GEMM row r is scaled by the maximum of ITS time row (rows of a GEMM are
+// independent, so a per-row power of two folds exactly into the epilogue) and the tile commits 8 output maxima.
 // K is walked in stages of 32: the x tile is loaded as full 128-byte row segments (float4 per lane), split to f16
 // hi/lo once and staged in LDS as [row][k] with an 96-byte row stride (conflict-free ds_read_b128 A fragments); the
 // weights arrive pre-split and pre-packed in B-fragment order (conv_pack.pack_linear) and go global -> LDS by DMA
@@ -171,6 +172,11 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
         for (int i = 0; i < E_ITERS; ++i) { int c; rr[0][i] = *reinterpret_cast<const float4*>(resid + out_offset(0, i, c)); }
     }
     __syncthreads();                     // every wave is done reading the stage buffers
+    // tile row & 7 = time row of the tile; 16 m and 64 wm are multiples of 8, so float4 i of this lane meets the SAME time row in
+    // every strip: its maximum is carried in a register across the strips and committed once
+    float vm[E_ITERS];
+#pragma unroll
+    for (int i = 0; i < E_ITERS; ++i) vm[i] = 0.f;
 #pragma unroll
     for (int m = 0; m < GM_MT; ++m) {
 #pragma unroll
@@ -194,12 +200,20 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
             v.x = fmaxf(v.x * sc + sh, 0.f); v.y = fmaxf(v.y * sc + sh, 0.f);
             v.z = fmaxf(v.z * sc + sh, 0.f); v.w = fmaxf(v.w * sc + sh, 0.f);
             if (RESID) { const float4 q = rr[m & 1][i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            if (out_amax) atomicMax(&s_tmax[tr & 7], __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
+            vm[i] = fmaxf(fmaxf(vm[i], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             *reinterpret_cast<float4*>(y + o) = v;
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (out_amax) {                      // max |y| per time row of the tile
+        // a row is ROW_F4 = 24 or 12 float4 long: aligned groups of four lanes always share a row -> two shuffles, then one LDS
+        // atomic per group (16 lanes per instruction instead of 64, E_ITERS instructions instead of 4 E_ITERS)
+#pragma unroll
+        for (int i = 0; i < E_ITERS; ++i) {
+            float a = fmaxf(vm[i], __shfl_xor(vm[i], 1, AC_WAVE));
+            a = fmaxf(a, __shfl_xor(a, 2, AC_WAVE));
+            if ((lane & 3) == 0) atomicMax(&s_tmax[((lane + 64 * i) / ROW_F4) & 7], __float_as_uint(a));
+        }
         __syncthreads();
         if (tid < 8 && s_tmax[tid]) atomicMax(reinterpret_cast<unsigned*>(out_amax + (size_t)item * T + tb * 8 + tid), s_tmax[tid]);
     }

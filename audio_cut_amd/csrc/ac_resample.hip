@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
         float* so = s_out + wave * 16 * OSTRIDE_DN;
         const size_t plane_out = (size_t)P;
         float vmax = 0.f;
+        float inv4;                      // e & 15 == lane & 15: every float4 of this lane belongs to the same four output pixels
+        (void)pix_scale(p0 + wm * 64 + 4 * (lane & 15), &inv4);
+        const float unscale = w_unscale * inv4;
 #pragma unroll
         for (int n = 0; n < RS_NT; ++n) {
 #pragma unroll
@@ -201,9 +204,6 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 const int co = nb * RS_BN + wn * 48 + n * 16 + nn;
                 if (co < Co) {
                     const float bv = bias[co];
-                    float inv4;
-                    (void)pix_scale(p0 + wm * 64 + 4 * q4, &inv4);
-                    const float unscale = w_unscale * inv4;
                     float4 v = *reinterpret_cast<const float4*>(&so[nn * OSTRIDE_DN + 4 * q4]);
                     v.x = fmaxf(v.x * unscale + bv, 0.f); v.y = fmaxf(v.y * unscale + bv, 0.f);
                     v.z = fmaxf(v.z * unscale + bv, 0.f); v.w = fmaxf(v.w * unscale + bv, 0.f);
@@ -236,6 +236,16 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
 #pragma unroll
             for (int i = 0; i < 3; ++i) { int nn; sk[0][i] = *reinterpret_cast<const float4*>(skip + out_offset(0, i, nn)); }
         }
+        // the 64 pixels of this wave lie in at most two input rows (W >= 64): row_a and row_a + 1, the second from pixel `bnd` on.
+        // Their two scales are wave-uniform; the four output maxima (2 input rows x dy) are carried across the strips.
+        const int pw0 = p0 + wm * 64;
+        const int row_a = __builtin_amdgcn_readfirstlane(pw0 / W);
+        const int row_b = row_a + 1 < H ? row_a + 1 : row_a;
+        const int bnd = (row_a + 1) * W;
+        float inv_a, inv_b;
+        (void)ac_act_scale(amax_in, row_a, row_a, 1.f, 0.f, &inv_a);
+        (void)ac_act_scale(amax_in, row_b, row_b, 1.f, 0.f, &inv_b);
+        float vrow[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int m = 0; m < RS_MT; ++m) {
 #pragma unroll
@@ -248,9 +258,8 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
             }
             __builtin_amdgcn_wave_barrier();
             float vmax[2] = {0.f, 0.f};          // output rows 2 yy (dy = 0) and 2 yy + 1 of this lane's input pixel pair
-            float inv2;
-            (void)pix_scale(p0 + wm * 64 + m * 16 + 2 * (lane & 7), &inv2);
-            const float unscale = w_unscale * inv2;
+            const bool second = pw0 + m * 16 + 2 * (lane & 7) >= bnd;     // W is even: a pixel pair shares its row
+            const float unscale = w_unscale * (second ? inv_b : inv_a);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 int nn;
@@ -267,12 +276,17 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 *reinterpret_cast<float4*>(out + o) = v;
                 vmax[dy] = fmaxf(fmaxf(vmax[dy], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
-            if (amax_slots) {
-                const int yy2 = 2 * ((p0 + wm * 64 + m * 16 + 2 * (lane & 7)) / W);
-                ac_amax_commit_blocks(vmax[0], yy2, amax_slots);
-                ac_amax_commit_blocks(vmax[1], yy2 + 1, amax_slots);
-            }
+            vrow[0][0] = fmaxf(vrow[0][0], second ? 0.f : vmax[0]); vrow[0][1] = fmaxf(vrow[0][1], second ? 0.f : vmax[1]);
+            vrow[1][0] = fmaxf(vrow[1][0], second ? vmax[0] : 0.f); vrow[1][1] = fmaxf(vrow[1][1], second ? vmax[1] : 0.f);
             __builtin_amdgcn_wave_barrier();
+        }
+        if (amax_slots) {
+            ac_amax_commit(vrow[0][0], amax_slots + 2 * row_a);
+            ac_amax_commit(vrow[0][1], amax_slots + 2 * row_a + 1);
+            if (row_b != row_a) {
+                ac_amax_commit(vrow[1][0], amax_slots + 2 * row_b);
+                ac_amax_commit(vrow[1][1], amax_slots + 2 * row_b + 1);
+            }
         }
     }
 }
@@ -292,6 +306,7 @@ static int rs_launch(int mode, ac_ctx* ctx, const float* x, const void* w_packed
     }
     AC_REQUIRE(P % RS_BM == 0, "pixels per image % 128 == 0");
     AC_REQUIRE(mode != 0 || !(in_amax || out_amax) || (W / 2) % 4 == 0, "down with amax: (W / 2) % 4 == 0 (a float4 of outputs stays in one row)");
+    AC_REQUIRE(mode != 1 || !(in_amax || out_amax) || (W >= 64 && W % 2 == 0), "up with amax: W >= 64 and even (a wave's 64 pixels lie in at most two rows)");
     AC_REQUIRE((long long)H * W * 4 < (1LL << 31), "plane too large");
     const int n_stage = (K + RS_BK - 1) / RS_BK, n_nblk = (N + RS_BN - 1) / RS_BN;
     const long long n_mblk = (long long)B * (P / RS_BM);

@@ -215,6 +215,19 @@ def test_first_conv_fused_into_the_3x3_loader_is_bit_identical(hip_ctx):
     ref2 = hip_ctx.conv3x3_f16x3(mid, wp, b3, 48, un, relu=True, in_amax=_blk_amax(mid))
     assert float((got2 - ref2).abs().max() / ref2.abs().max()) < 1e-6
     assert torch.equal(oa, _blk_amax(got2))
+    # a burst's leakage into digital silence (rows falling by 1e-3 each, then exact zeros), bias-free like the synthetic net: the
+    # fused kernel's row-exact path holds every element to float32-class accuracy relative to its OWN sum |x||w|
+    import torch.nn.functional as F
+    ramp = torch.zeros(16, dtype=torch.float64); ramp[:3] = 1.0; ramp[3:12] = 1e-3 ** torch.arange(1, 10, dtype=torch.float64)
+    spec_c = (spec.cpu() * ramp.float().view(1, 1, -1, 1)).to(dev)
+    zb1 = torch.zeros(48, device=dev); zb3 = torch.zeros(48, device=dev)
+    got3 = hip_ctx.conv3x3_f16x3_first(spec_c, w1, zb1, wp, zb3, 48, un, relu=True, spec_amax=_blk_amax(spec_c), amax_gain=gain, amax_offs=0.0)
+    mid64 = F.relu(F.conv2d(spec_c.double().cpu(), w1.double().cpu()))
+    ref64 = F.relu(F.conv2d(mid64, w3.double(), padding=1)); sc64 = F.conv2d(mid64.abs(), w3.abs().double(), padding=1)
+    mid32 = F.relu(F.conv2d(spec_c.cpu(), w1.cpu()))
+    e32 = _elementwise_error(F.relu(F.conv2d(mid32, w3, padding=1)), ref64, sc64)
+    e16 = _elementwise_error(got3.cpu(), ref64, sc64)
+    assert e16 <= 4.0 * e32 + 2.0 ** -24, (e16, e32)
 
 
 def _blk_amax(t: torch.Tensor) -> torch.Tensor:
@@ -231,7 +244,8 @@ def _elementwise_error(y: torch.Tensor, ref64: torch.Tensor, scale64: torch.Tens
 def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
     """The per-item activation scale (include/audiocut_hip.h, "amax"): every split-float16 kernel is fed inputs from 1e-6 to 1e6
     (past the float16 range: nothing saturates), uniform and with a 1e-8 decay along the time axis inside one item (the scale is
-    local in time: the rows one accumulation reads), and its
+    local in time: the rows one accumulation reads; the two "cliff" cases - rows falling by 1e-2 resp. 1e-9 EACH into exact zeros,
+    the leakage next to a burst in digital silence - take the conv kernels' row-exact path, ac_common.h), and its
     ELEMENT-WISE error against float64 must stay within 4x of what a true float32 evaluation (PyTorch CPU float32) of the same
     layer delivers.  Without the scale the 1e-6 and decaying cases are 2-4 orders of magnitude worse (the low float16 part is
     a subnormal) and the 1e6 case clips.  out_amax must be the exact per-item maximum of the result."""
@@ -241,15 +255,24 @@ def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
     dev = hip_ctx.device
     mags = (1e-6, 1e-3, 1.0, 3.0e2, 6.0e4, 1.0e6)
     worst = {}
+    failures = []
 
     def check(name, run, ref_fn, x, has_bias_scale):
         """run(x_dev, in_amax, out_amax) -> y ; ref_fn(x, dtype) -> (y, scale) on the CPU in `dtype`."""
         for mag in mags:
-            for decay in (False, True):
+            for decay in (False, True, "cliff", "cliff9"):
+                if decay in ("cliff", "cliff9") and not (1e-3 <= mag <= 3.0e2):
+                    continue            # the cliffs already span 28 decades: keep their products clear of float32 subnormals
                 xm = x * mag
-                if decay:       # item 0 keeps its level, item 1 falls by 1e-8 along H (time): a decay into silence inside one item
+                if decay is True:       # item 0 keeps its level, item 1 falls by 1e-8 along H (time): a decay into silence inside one item
                     ramp = torch.logspace(0, -8, x.shape[2], dtype=torch.float32).view(1, 1, -1, 1)
                     xm = torch.cat([xm[:1], xm[1:] * ramp], dim=0)
+                elif decay:             # the leakage of a burst into digital silence: rows fall by 1e-2 (1e-9) each, then exact zeros
+                    ramp = torch.zeros(x.shape[2], dtype=torch.float64)
+                    ramp[:5] = 1.0
+                    n, step = (14, 1e-2) if decay == "cliff" else (3, 1e-9)
+                    ramp[5:5 + n] = step ** torch.arange(1, n + 1, dtype=torch.float64)
+                    xm = torch.cat([xm[:1], xm[1:] * ramp.float().view(1, 1, -1, 1)], dim=0)
                 ia = _blk_amax(xm).to(dev)
                 y = run(xm.to(dev), ia, None)
                 oa = torch.zeros((x.shape[0], y.shape[2]), device=dev)
@@ -259,7 +282,8 @@ def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
                 e16 = _elementwise_error(y.cpu(), ref64, scale64)
                 e32 = _elementwise_error(y32, ref64, scale64)
                 worst[name] = max(worst.get(name, 0.0), e16 / max(e32, 1e-12))
-                assert e16 <= 4.0 * e32 + 2.0 ** -24, (name, mag, decay, e16, e32)
+                if not e16 <= 4.0 * e32 + 2.0 ** -24:
+                    failures.append((name, mag, decay, e16, e32))
 
     # --- 3x3 convs: 16-channel-stage kernel, 96-channel and 48-channel 8-channel-stage kernels
     for ci, co, h, w_, kind in ((48, 48, 64, 32, "plain"), (96, 96, 64, 32, "w96"), (48, 48, 64, 32, "s8"), (144, 144, 64, 32, "s8")):
@@ -302,7 +326,7 @@ def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
         return F.relu(F.conv2d(xx, wd.to(dt), None, stride=2)).double(), F.conv2d(xx.abs().double(), wd.abs().double(), None, stride=2)
     check("down", lambda xd, ia, oa: hip_ctx.down2x_f16x3(xd, wpd, zb, c + 48, un, in_amax=ia, out_amax=oa), ref_dn, x, False)
     c2 = 96
-    x = torch.randn(2, c2, 32, 32, generator=g)
+    x = torch.randn(2, c2, 32, 64, generator=g)          # W >= 64: a wave's 64 pixels lie in at most two rows (the net's narrowest is 96)
     wu = torch.randn(c2, c2 - 48, 2, 2, generator=g) / np.sqrt(c2)
     packed, un2 = pack_linear(wu.numpy().transpose(1, 2, 3, 0).reshape(-1, c2), bn=96)
     wpu = torch.from_numpy(packed.view(np.int16)).to(dev); zb2 = torch.zeros(c2 - 48, device=dev)
@@ -311,6 +335,7 @@ def test_split_f16_kernels_are_float32_class_at_every_magnitude(hip_ctx):
         return F.relu(F.conv_transpose2d(xx, wu.to(dt), None, stride=2)).double(), F.conv_transpose2d(xx.abs().double(), wu.abs().double(), None, stride=2)
     check("up", lambda xd, ia, oa: hip_ctx.up2x_f16x3(xd, wpu, zb2, c2 - 48, un2, in_amax=ia, out_amax=oa), ref_up, x, False)
     print("worst element-wise error relative to a float32 evaluation:", {k: f"{v:.2f}x" for k, v in worst.items()})
+    assert not failures, failures
     # and what the scale buys: the same 1e-6 input WITHOUT it is orders of magnitude off element-wise
     x = torch.randn(2, 48, 16, 64, generator=g) * 1e-6
     wt = torch.randn(48, 48, 3, 3, generator=g) / np.sqrt(9 * 48)
