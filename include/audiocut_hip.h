@@ -178,6 +178,8 @@ int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int
  * low part stays a normal float16 down to 2^-17 of the LOCAL peak and the representation error is
  * max(2^-22 |x|, 2^-40 local max) instead of max(2^-22 |x|, 3e-8) - float32-class relative accuracy for quiet items, for
  * decays into silence and for the leakage next to a loud passage (where the quiet guard decides), and no saturation at 65504.
+ * A 3x3 conv tile whose ten row maxima span more than 2^12 takes the kernels' row-exact path instead: every patch row staged at its
+ * own scale, every output row accumulated at the scale of the loudest of its three input rows (csrc/ac_common.h).
  * out_amax [B][H_out] (zeroed by the caller before the launch) receives max |out| per item and row by ordered-bits atomicMax.
  * Either may be NULL: no scaling (the pre-ABI-2 behaviour) / no reduction. */
 int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
