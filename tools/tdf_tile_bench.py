@@ -3,6 +3,7 @@ usage: python tools/tdf_tile_bench.py [batch]     (AC_TDF_NARROW=1 in a scratch 
 import os, sys, hashlib, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_cut_amd import _native
+from audio_cut_amd._native import _ptr, _stream, _check
 from audio_cut_amd.separation.conv_pack import pack_linear
 hip = _native.Context()
 dev = hip.device
@@ -20,8 +21,10 @@ for c, t, f in ((48, 256, 3072), (96, 128, 1536), (144, 64, 768)):
         wp = torch.from_numpy(packed.view(np.int16)).to(dev)
         ia = x.abs().amax(dim=(1, 3)).contiguous()
         oa = torch.zeros((B, t), device=dev)
-        run = lambda: hip.tdf_linear_f16x3(x, wp, n, sc, sh, un, resid=resid, in_amax=ia, out_amax=oa)
-        out = run(); torch.cuda.synchronize()
+        out = torch.empty((B, c, t, n), device=dev)        # allocated once: a 4.8 GB torch.empty inside the timed loop is not free
+        run = lambda: _check(hip.lib.ac_tdf_linear_f16x3(hip._h, _ptr(x), _ptr(wp), _ptr(sc), _ptr(sh), _ptr(resid), _ptr(out), B * c * t, n, k,
+                                                         t, c, float(un), _ptr(ia), _ptr(oa), _stream()))
+        run(); run(); torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
