@@ -632,7 +632,7 @@ class Context:
                         shift1: torch.Tensor, scale2: torch.Tensor, shift2: torch.Tensor,
                         out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x + relu(bn(linear(relu(bn(linear(x)))))) over the last axis, both narrow TDF layers in one exact-float32 kernel
-        (`conv_pack.pack_tdf_small` weights; F % 16 == 0, hidden <= 48)."""
+        (`conv_pack.pack_tdf_small` weights; F % 32 == 0, hidden <= 48)."""
         if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
             raise NativeError("tdf_small_fused expects a contiguous float32 NCHW tensor")
         b, c, t, f = x.shape

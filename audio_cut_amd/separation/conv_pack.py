@@ -140,8 +140,8 @@ def pack_linear(weight: np.ndarray, bn: int = 0) -> Tuple[np.ndarray, float]:
 
 
 def tdf_small_tileable(f: int, hidden: int, rows: int) -> bool:
-    """shapes `ac_tdf_small_fused` takes: F % 16 == 0, bottleneck <= 48, rows % 32 == 0."""
-    return f % 16 == 0 and 0 < hidden <= 48 and rows % 32 == 0
+    """shapes `ac_tdf_small_fused` takes: F % 32 == 0, bottleneck <= 48, rows % 32 == 0."""
+    return f % 32 == 0 and 0 < hidden <= 48 and rows % 32 == 0
 
 
 def pack_tdf_small(w1: np.ndarray, w2: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

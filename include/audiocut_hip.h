@@ -206,7 +206,7 @@ int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const
 /* Both TDF layers + residual of a block at the deep levels (F = 384 / 192 / 96, bottleneck Hd = F / 8 <= 48: too narrow for
  * ac_tdf_linear_f16x3), one kernel, exact float32 on v_mfma_f32_16x16x4_f32 (same graph nodes as ac_tdf_linear_f16x3):
  *   y[m][n] = x[m][n] + relu(scale2[c] * sum_j relu(scale1[c] * sum_f x[m][f] w1[j][f] + shift1[c]) w2[n][j] + shift2[c])
- * w1_packed / w2_packed from conv_pack.pack_tdf_small.  M % 32 == 0, F % 16 == 0, x != y.  out_amax [M / (C*T)][T] as above
+ * w1_packed / w2_packed from conv_pack.pack_tdf_small.  M % 32 == 0, F % 32 == 0, x != y.  out_amax [M / (C*T)][T] as above
  * (needs (C * T) % 32 == 0); no in_amax: nothing is split. */
 int ac_tdf_small_fused(ac_ctx* ctx, const float* x, const void* w1_packed, const void* w2_packed, const float* scale1,
                        const float* shift1, const float* scale2, const float* shift2, float* y, long long M, int F, int Hd,
