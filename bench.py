@@ -446,13 +446,16 @@ def main() -> None:
         }
         if world == 1:
             # single-stream latency next to the pipelined throughput: one more track, strictly alone on the GPU (outside the timed region)
-            torch.cuda.synchronize()
-            tl = time.perf_counter()
-            lat = splitters[0].split_track(tracks[0], audio_dev=tracks_dev[0])
-            torch.cuda.synchronize()
-            out["single_stream_latency_ms"] = round((time.perf_counter() - tl) * 1e3, 2)
-            out["single_stream_latency_note"] = "one track alone on the GPU (pipeline depth 1, host tail not overlapped); same result: " + \
-                str(lat["sample_boundaries"] == step_results[0]["sample_boundaries"])
+            lat_ms = []
+            for _ in range(3):           # the median of three: a single probe caught allocator / clock hiccups of 2-3x now and then
+                torch.cuda.synchronize()
+                tl = time.perf_counter()
+                lat = splitters[0].split_track(tracks[0], audio_dev=tracks_dev[0])
+                torch.cuda.synchronize()
+                lat_ms.append((time.perf_counter() - tl) * 1e3)
+            out["single_stream_latency_ms"] = round(sorted(lat_ms)[1], 2)
+            out["single_stream_latency_note"] = "one track alone on the GPU (pipeline depth 1, host tail not overlapped), median of " + \
+                str([round(v, 1) for v in lat_ms]) + "; same result: " + str(lat["sample_boundaries"] == step_results[0]["sample_boundaries"])
             out["framewise_rooflines"] = framewise_rooflines(hip, tracks_dev[0])
         if world == 1 and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds, weights, spec)

@@ -401,6 +401,33 @@ def test_soak_track_on_a_threshold_crossing_is_exact(hip_ctx, golden_dir):
     assert stem_err < 3e-6
 
 
+@pytest.mark.parametrize("seconds,seed,weight_seed,name", [(200.0, 79, 29, "c1_200s_seed79_w29_oracle"),
+                                                          (120.0, 71, 21, "c1_120s_seed71_w21_oracle")])
+def test_soak_tracks_decided_in_digital_silence_are_exact(hip_ctx, golden_dir, seconds, seed, weight_seed, name):
+    """The two round-2 live-soak tracks that a per-8-row activation scale left open: guard boundaries inside the
+    digital silence between sine bursts, where the oracle's own dB series is one flat plateau and np.argmin returns the first
+    sample at which the U-Net's leakage - 1e-14 of the neighbouring burst, falling by 0.2 % per sample - stops being resolved
+    against the 1e-12 epsilon.  One scale per item moved them by up to 84 samples, one per time row by up to 30; with the conv
+    kernels' row-exact path (csrc/ac_common.h) every index is the oracle's."""
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    g = np.load(golden_dir / f"{name}.npz")
+    mix = signals.c1_sine_silence(seconds, seed=seed)
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=weight_seed), ctx=hip_ctx, max_items_per_forward=32)
+    backend.load_model()
+    res = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend)).split_track(mix)
+    got, want = res["sample_boundaries"], g["sample_boundaries"].tolist()
+    stem_err = float(np.max(np.abs(res["vocal_track"][: 4 * SR: 7] - g["vocal_head"]))) / float(g["vocal_peak"])
+    print(f"{name}: stem error {stem_err:.2e} of peak, moved boundaries {[(a, b) for a, b in zip(got, want) if a != b]}")
+    assert got == want
+    assert res["cuts_samples"] == g["cuts"].tolist()
+    assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
+    assert np.array_equal(np.asarray([p.cut_point for p in res["pauses"]]), g["pause_cut_points"])
+    assert stem_err < 5e-6
+
+
 def test_track_pipeline_matches_sequential_processing(hip_ctx):
     """BASELINE config C3 in miniature: six different tracks through `batch.TrackPipeline` (two in flight, own streams,
     shared U-Net weights) give, track by track, exactly what processing them one after the other gives."""

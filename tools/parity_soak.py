@@ -1,5 +1,7 @@
 """Parity soak: the GPU path against the CPU oracle, live, on tracks / weights no fixture covers.
-usage: python tools/parity_soak.py "dur,song_seed,weight_seed[,generator]" ...   (one progress line per case)"""
+usage: python tools/parity_soak.py "dur,song_seed,weight_seed[,generator[,silero_seed]]" ...   (one progress line per case)
+With a silero_seed the chunked VAD is the Silero network (HIP kernels vs oracle/silero.py) on seeded synthetic weights calibrated on
+bursts (tests/silero_synth.py) instead of the no-weights energy gate."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 torch.set_num_threads(16)
@@ -9,7 +11,9 @@ from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
 from audio_cut_amd.separation.backends import MDX23HipBackend
 from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
 from audio_cut_amd.testing import signals
-from oracle import e2e as OE, refine as OR
+from audio_cut_amd import config as C
+from oracle import e2e as OE, refine as OR, silero as OS
+import tempfile, os
 OR.LEGACY_PROMOTION = True
 hip = _native.Context()
 ok_all = True
@@ -17,22 +21,34 @@ for arg in sys.argv[1:]:
     parts = arg.split(",")
     dur, sseed, wseed = float(parts[0]), int(parts[1]), int(parts[2])
     gen = parts[3] if len(parts) > 3 else "c2_song"
+    silero_seed = int(parts[4]) if len(parts) > 4 else None
     w = synth_weights(TfcTdfSpec(), seed=wseed)
     backend = MDX23HipBackend(weights=w, ctx=hip, max_items_per_forward=32); backend.load_model()
-    sp = SeamlessSplitter(44100, separator=EnhancedVocalSeparator(44100, backend=backend))
-    mix = getattr(signals, gen)(dur, seed=sseed)
-    mix = np.mean(mix, axis=0).astype(np.float32) if mix.ndim == 2 else mix
-    t0 = time.time(); r = sp.split_track(mix); tg = time.time() - t0
-    t0 = time.time(); ref = OE.run_track(mix, 44100, w); to = time.time() - t0
+    saved = C.snapshot(); vad_fn = None
+    if silero_seed is not None:
+        from tests.silero_synth import synth_silero_weights
+        sw = synth_silero_weights(silero_seed, calib="bursts")
+        wpath = os.path.join(tempfile.mkdtemp(), "silero.npz"); np.savez(wpath, **sw)
+        C.set_runtime_config({"advanced_vad.silero_weights_path": wpath})
+        vad_fn = OS.silero_vad_fn(44100, sw)
+    try:
+        sp = SeamlessSplitter(44100, separator=EnhancedVocalSeparator(44100, backend=backend))
+        mix = getattr(signals, gen)(dur, seed=sseed)
+        mix = np.mean(mix, axis=0).astype(np.float32) if mix.ndim == 2 else mix
+        t0 = time.time(); r = sp.split_track(mix); tg = time.time() - t0
+    finally:
+        C.restore(saved)
+    t0 = time.time(); ref = OE.run_track(mix, 44100, w, **({"vad_fn": vad_fn} if vad_fn is not None else {})); to = time.time() - t0
     cuts_ref = ref.policy.cuts if ref.policy is not None else [0, len(mix)]
     flags_ref = ref.policy.flags if ref.policy is not None else None
     peak = float(np.max(np.abs(ref.vocal))) or 1.0
     stem = float(np.max(np.abs(r["vocal_track"] - ref.vocal))) / peak
     rms = float(np.max(np.abs(np.asarray(r["feature_cache"].rms_series) - np.asarray(ref.cache.rms_series)) / (np.abs(np.asarray(ref.cache.rms_series)) + 1e-7)))
     ok = (r["sample_boundaries"] == ref.sample_boundaries and r["cuts_samples"] == cuts_ref and
-          (flags_ref is None or [bool(f) for f in r["segment_vocal_flags"]] == [bool(f) for f in flags_ref]) and stem < 1e-4)
+          (flags_ref is None or [bool(f) for f in r["segment_vocal_flags"]] == [bool(f) for f in flags_ref]) and stem < 1e-4 and
+          (silero_seed is None or r["vad_segments"] == ref.vad_segments))
     ok_all &= ok
-    print(f"{gen} {dur:g}s song_seed={sseed} weights_seed={wseed}: guard boundaries {len(ref.sample_boundaries)} "
+    print(f"{gen} {dur:g}s song_seed={sseed} weights_seed={wseed}" + (f" silero_seed={silero_seed} vad_segments={len(ref.vad_segments)}" if silero_seed is not None else "") + f": guard boundaries {len(ref.sample_boundaries)} "
           f"manifest cuts {len(cuts_ref)} pauses {len(ref.pauses)} | exact={ok} stem_err={stem:.2e} rms_series_rel={rms:.2e} | gpu {tg:.2f}s oracle {to:.0f}s", flush=True)
     if not ok:
         print("  gpu   :", r["sample_boundaries"], r["cuts_samples"]); print("  oracle:", ref.sample_boundaries, cuts_ref)
