@@ -51,27 +51,21 @@ __device__ inline int cv_phys(int c) { return c ^ (((c >> 2) & 1) << 1); } // st
 #define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
 #define CV_OUT_STRIDE (CV_TW + 4)                                          // floats per (co, row) line of the output staging
 
-// FIRST = true fuses the graph's first 1x1 convolution (C0 <= 8 spectrogram channels -> C_in, + bias + ReLU) into the
-// loader: x is the [B][C0][H][W] spectrogram, the C_in-channel tensor the 3x3 conv consumes is generated per staged
-// pixel (w1 [C_in][C0], b1 [C_in]; float32 FMAs in ac_conv1x1_small's order, so the values are bit-identical to running
-// that kernel first) and never touches HBM.
-template <bool RELU, bool FIRST>
+template <bool RELU>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int C_in, int C_out, int H, int W, float w_unscale, int bw,
-                                                          const float* __restrict__ w1, const float* __restrict__ b1, int C0,
-                                                          const float* __restrict__ in_amax, float* __restrict__ out_amax,
-                                                          float amax_gain, float amax_offs) {
+                                                          const float* __restrict__ in_amax, float* __restrict__ out_amax) {
     // one LDS arena: [hi patch | lo patch | weight fragments] during the K loop, re-used as the output staging tile
     // The plain kernel (DMA) double-buffers the weight fragments - even stages (4 k-steps) in one buffer, odd stages (5) in
     // the other - and fills them with global_load_lds (no registers, issued a stage ahead): 25,600 + 24,576 + 30,720 =
-    // 80,896 B, two workgroups per CU still fit the 160 KB.  The FIRST kernel keeps one register-staged buffer.
-    constexpr bool DMA = !FIRST;
+    // 80,896 B, two workgroups per CU still fit the 160 KB.
+    constexpr bool DMA = true;
     constexpr int PATCH_BYTES = 2 * CV_PH * CV_LW * CV_PIX_STRIDE * 2;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[PATCH_BYTES + (DMA ? (CV_WFRAGS_PAIRS + CV_WFRAGS) : CV_WFRAGS) * 16];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + CV_PH * CV_LW * CV_PIX_STRIDE;
-    f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw + PATCH_BYTES);            // even stages (and every stage of the FIRST kernel)
+    f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw + PATCH_BYTES);            // even stages
     f16x8* s_w1 = DMA ? s_w0 + CV_WFRAGS_PAIRS : s_w0;                         // odd stages
     float* s_out = reinterpret_cast<float*>(s_raw);       // [48 co][8 rows][CV_OUT_STRIDE] = 55296 B <= arena (56320 B)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,14 +87,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     const int y0 = (t / bw) * CV_TH, x0 = (band * bw + t % bw) * CV_TW;
     const int n_cb = C_in / CV_CB;
     const size_t plane = (size_t)H * W;
-    const float* xb = x + (size_t)b * (FIRST ? C0 : C_in) * plane;
-    // time-local power-of-two activation scale (ac_common.h): log2 scale of each patch row y0 - 1 .. y0 + 8.  FIRST: in_amax is
-    // max|spectrogram| per row; the tensor that is split is the generated relu(w1 x + b1), bounded per row by
-    // amax * max_c sum_j |w1[c][j]| + max_c |b1[c]| (amax_gain, amax_offs from the host)
+    const float* xb = x + (size_t)b * C_in * plane;
+    // time-local power-of-two activation scale (ac_common.h): log2 scale of each patch row y0 - 1 .. y0 + 8
     __shared__ int s_ex[CV_PH + 2];
     if (tid < CV_PH + 2) {
         const int gy = y0 - 1 + tid;
-        s_ex[tid] = (in_amax && tid < CV_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy] * amax_gain + amax_offs) : AC_EX_NONE;
+        s_ex[tid] = (in_amax && tid < CV_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy]) : AC_EX_NONE;
     }
     __syncthreads();
     int ex_min = AC_EX_NONE, ex_max = -AC_EX_NONE;
@@ -151,15 +143,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
     }
     float4 pre_x[CV_ACT_ITERS][4];
     f16x8 pre_w[CV_W_ITERS];
-    __shared__ float s_first[FIRST ? 5 * 64 : 1];        // FIRST: [channel][w1[0..3], b1] of the fused 1x1 conv (C_in <= 64)
-    if (FIRST) {
-        for (int c = tid; c < C_in; c += 256) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s_first[c * 5 + j] = (j < C0) ? w1[c * C0 + j] : 0.f;
-            s_first[c * 5 + 4] = b1[c];
-        }
-    }
-
     auto prefetch = [&](int cb) {
         const f16x8* wcb = wbase + (size_t)cb * CV_WFRAGS;
         if (DMA) {
@@ -183,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ci = FIRST ? q : cb * CV_CB + (a_c4[i] < 0 ? 0 : a_c4[i]) * 4 + q;      // FIRST: the spectrogram's channels
-                pre_x[i][q] = (a_src[i] >= 0 && (!FIRST || q < C0)) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_src[i])
+                const int ci = cb * CV_CB + (a_c4[i] < 0 ? 0 : a_c4[i]) * 4 + q;
+                pre_x[i][q] = (a_src[i] >= 0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_src[i])
                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -225,29 +208,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                 const int e = s_ex[a_off[i] / (CV_LW * CV_PIX_STRIDE)];
                 a_s = e == AC_EX_NONE ? 1.f : ldexpf(1.f, e);
             }
-            float gen[4][4];                                           // FIRST: [virtual channel q][pixel k]
-            if (FIRST) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = cb * CV_CB + a_c4[i] * 4 + q;
-                    const float wv[4] = {s_first[c * 5], s_first[c * 5 + 1], s_first[c * 5 + 2], s_first[c * 5 + 3]};
-                    const float bv = s_first[c * 5 + 4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float a = bv;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < C0) a = fmaf(wv[j], v4[j][k], a);
-                        gen[q][k] = (a_src[i] >= 0) ? fmaxf(a, 0.f) : 0.f;       // zero padding applies to the conv input, not to relu(b1)
-                    }
-                }
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                              // 4 pixels of the float4
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fminf(fmaxf((FIRST ? gen[q][k] : v4[q][k]) * a_s, -65504.f), 65504.f);
+                    const float v = fminf(fmaxf(v4[q][k] * a_s, -65504.f), 65504.f);
                     const _Float16 hv = (_Float16)v;                   // v_cvt_f16_f32, round to nearest even
                     h4[q] = f16_bits(hv);
                     l4[q] = f16_bits((_Float16)(v - (float)hv));
@@ -355,8 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
 }
 
 static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
-                     int H, int W, float w_unscale, int relu, void* stream, const float* w1, const float* b1, int C0,
-                     const float* in_amax, float* out_amax, float amax_gain, float amax_offs) {
+                     int H, int W, float w_unscale, int relu, void* stream, const float* in_amax, float* out_amax) {
     AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
     AC_REQUIRE(B > 0 && C_in > 0 && C_in % CV_CB == 0 && C_out > 0 && C_out % CV_COB == 0, "C_in % 16 == 0 and C_out % 48 == 0");
     AC_REQUIRE(H > 0 && H % CV_TH == 0 && W > 0 && W % CV_TW == 0, "H % 8 == 0 and W % 32 == 0");
@@ -368,14 +333,8 @@ static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const fl
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
     const f16x8* wp = (const f16x8*)w_packed;
-    if (w1) {
-        AC_REQUIRE(b1 && C0 >= 1 && C0 <= 4 && C_in <= 64, "fused first conv: 1 <= C0 <= 4, C_in <= 64");
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0, in_amax, out_amax, amax_gain, amax_offs);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, C0, in_amax, out_amax, amax_gain, amax_offs);
-    } else {
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0, in_amax, out_amax, 1.f, 0.f);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3<false, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, w1, b1, 0, in_amax, out_amax, 1.f, 0.f);
-    }
+    if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3<true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
+    else      hipLaunchKernelGGL((k_conv3x3_f16x3<false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -383,16 +342,5 @@ static int cv_launch(ac_ctx* ctx, const float* x, const void* w_packed, const fl
 extern "C" int ac_conv3x3_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                                  int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax,
                                  void* stream) {
-    return cv_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, nullptr, nullptr, 0, in_amax, out_amax,
-                     1.f, 0.f);
-}
-
-extern "C" int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,
-                                       const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W,
-                                       float w_unscale, int relu, const float* spec_amax, float amax_gain, float amax_offs,
-                                       float* out_amax, void* stream) {
-    AC_REQUIRE(w1 && b1, "null pointer");
-    AC_REQUIRE(amax_gain >= 0.f && amax_offs >= 0.f, "amax bound terms must be non-negative");
-    return cv_launch(ctx, spec, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, w1, b1, C0, spec_amax, out_amax,
-                     amax_gain, amax_offs);
+    return cv_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, stream, in_amax, out_amax);
 }

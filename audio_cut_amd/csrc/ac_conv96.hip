@@ -28,16 +28,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define W9_CB 8                  // input channels per stage
 #define W9_PATCH_BYTES (2 * W9_PH * W9_RS * W9_CB * 2)
 #define W9_OUT_STRIDE (W9_TW + 4)
+#ifndef W9_FIRST_OCC
+#define W9_FIRST_OCC 3               // workgroups per CU of the fused first conv
+#endif
 
 __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
 // MT = 16-row output-channel tiles per workgroup: 6 (96 channels, two workgroups per CU) or 3 (48 channels, three per CU).
 // ROWX: the row-exact path of ac_common.h (per-row staging scales, power-of-two fragment factors); s_ex = log2 scale per patch row.
-template <int MT, bool RELU, bool ROWX>
+// FIRST fuses the graph's first 1x1 convolution (C0 <= 4 spectrogram channels -> C_in, + bias + ReLU) into the loader: x is the
+// [B][C0][H][W] spectrogram, a thread's four spectrogram float4 are loaded ONCE and every stage's 8 channels are generated from
+// them per staged pixel (s_first = [C_in][w1[0..3], b1] in LDS; float32 FMAs in ac_conv1x1_small's order, so the values are
+// bit-identical to running that kernel first) - the C_in-channel tensor never touches HBM and the K loop has no activation loads.
+template <int MT, bool RELU, bool ROWX, bool FIRST>
 __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8* __restrict__ wpk, const float* __restrict__ bias,
                                         float* __restrict__ out, int C_in, int C_out, int H, int W, float w_unscale,
                                         float* __restrict__ out_amax, unsigned char* s_raw, const int* s_ex, int ex_min,
-                                        int cob, int b, int y0, int x0) {
+                                        int cob, int b, int y0, int x0, const float* s_first, int C0) {
     constexpr int W9_MT = MT, W9_COB = 16 * MT;
     constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
     constexpr int EP_M = (MT == 6) ? 3 : 2;                   // row tiles per epilogue pass (the output tile must fit the arena)
@@ -50,7 +57,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     const int g = lane >> 4, px = lane & 15;
     const int n_cb = C_in / W9_CB;                                             // even: the stage that issues a shared step is always odd
     const size_t plane = (size_t)H * W;
-    const float* xb = x + (size_t)b * C_in * plane;
+    const float* xb = x + (size_t)b * (FIRST ? C0 : C_in) * plane;
     // staging: thread -> (row 0..9, column quad 0..9, channel quad 0..1): one aligned float4 (4 pixels) of 4 channels each
     const int a_c4 = tid & 1, a_rest = tid >> 1;
     const int a_row = a_rest / 10, a_qd = a_rest - a_row * 10;
@@ -90,8 +97,8 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     auto prefetch_x = [&](int cb, float4 (&pxr)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ci = cb * W9_CB + a_c4 * 4 + q;
-            pxr[q] = *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_ld);
+            const int ci = FIRST ? q : cb * W9_CB + a_c4 * 4 + q;               // FIRST: the spectrogram's channels, fetched once
+            pxr[q] = (!FIRST || q < C0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_ld) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto prefetch_w = [&](int cb) {
@@ -113,12 +120,29 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         if (a_live) {
             const float zs = a_src >= 0 ? act_s : 0.f;         // zero padding (and the idle slots of a row)
             const float* v4[4] = {&pxr[0].x, &pxr[1].x, &pxr[2].x, &pxr[3].x};
+            float gen[4][4];                                   // FIRST: [channel q of this thread's quad][pixel k]
+            if (FIRST) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* wf = s_first + (cb * W9_CB + a_c4 * 4 + q) * 5;
+                    const float wv[4] = {wf[0], wf[1], wf[2], wf[3]};
+                    const float bv = wf[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float a = bv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < C0) a = fmaf(wv[j], v4[j][k], a);
+                        gen[q][k] = fmaxf(a, 0.f);             // zero padding applies to the conv input (zs = 0), not to relu(b1)
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 unsigned short h4[4], l4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = fminf(fmaxf(v4[q][k] * zs, -65504.f), 65504.f);
+                    const float v = fminf(fmaxf((FIRST ? gen[q][k] : v4[q][k]) * zs, -65504.f), 65504.f);
                     const _Float16 hv = (_Float16)v;
                     h4[q] = w9_bits(hv);
                     l4[q] = w9_bits((_Float16)(v - (float)hv));
@@ -130,7 +154,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         }
         __builtin_amdgcn_s_waitcnt(0);   // this stage's weight fragments have landed
         __syncthreads();
-        if (cb + 1 < n_cb) { prefetch_w(cb + 1); prefetch_x(cb + 1, pxr); }
+        if (cb + 1 < n_cb) { prefetch_w(cb + 1); if (!FIRST) prefetch_x(cb + 1, pxr); }
         const f16x8* s_w = (cb & 1) ? s_w1 : s_w0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -222,17 +246,27 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     }
 }
 
-template <int MT, int OCC, bool RELU>
+template <int MT, int OCC, bool RELU, bool FIRST>
 __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __restrict__ x, const f16x8* __restrict__ wpk,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int C_in, int C_out, int H, int W, float w_unscale, int bw,
-                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax) {
+                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1, int C0,
+                                                              float amax_gain, float amax_offs) {
     constexpr int W9_COB = 16 * MT, W9_KFR = 2 * MT * 64, EP_M = (MT == 6) ? 3 : 2;
     constexpr int EP_BYTES = EP_M * 16 * W9_TH * W9_OUT_STRIDE * 4;
     constexpr int K_BYTES = W9_PATCH_BYTES + (2 + 3) * W9_KFR * 16;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[K_BYTES > EP_BYTES ? K_BYTES : EP_BYTES];
     __shared__ int s_ex[W9_PH + 2];
+    __shared__ float s_first[FIRST ? 5 * 64 : 1];        // FIRST: [channel][w1[0..3], b1] of the fused 1x1 conv (C_in <= 64)
     const int tid = threadIdx.x;
+    if (FIRST) {
+        for (int c = tid; c < C_in; c += 256) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_first[c * 5 + j] = (j < C0) ? w1[c * C0 + j] : 0.f;
+            s_first[c * 5 + 4] = b1[c];
+        }
+    }
     const int n_cob = C_out / W9_COB;
     const int tiles_x = W / W9_TW, tiles_y = H / W9_TH;
     int wi = blockIdx.x;                                                       // XCD-aware order as in ac_conv.hip
@@ -244,10 +278,12 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     const int band = t / (tiles_y * bw);
     t -= band * (tiles_y * bw);
     const int y0 = (t / bw) * W9_TH, x0 = (band * bw + t % bw) * W9_TW;
-    // time-local power-of-two activation scale (ac_common.h): log2 scale of each patch row y0 - 1 .. y0 + 8
+    // time-local power-of-two activation scale (ac_common.h): log2 scale of each patch row y0 - 1 .. y0 + 8.  FIRST: in_amax is
+    // max |spectrogram| per row; the tensor that is split is the generated relu(w1 x + b1), bounded per row by
+    // amax * max_c sum_j |w1[c][j]| + max_c |b1[c]| (amax_gain, amax_offs from the host; 1 and 0 otherwise: exact)
     if (tid < W9_PH + 2) {
         const int gy = y0 - 1 + tid;
-        s_ex[tid] = (in_amax && tid < W9_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy]) : AC_EX_NONE;
+        s_ex[tid] = (in_amax && tid < W9_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy] * amax_gain + amax_offs) : AC_EX_NONE;
     }
     __syncthreads();
     int ex_min = AC_EX_NONE, ex_max = -AC_EX_NONE;
@@ -259,13 +295,14 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     ex_min = __builtin_amdgcn_readfirstlane(ex_min);
     ex_max = __builtin_amdgcn_readfirstlane(ex_max);
     if (ex_min != AC_EX_NONE && ex_max - ex_min > AC_ROWX_SPREAD)
-        w9_tile<MT, RELU, true>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0);
+        w9_tile<MT, RELU, true, FIRST>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0, s_first, C0);
     else
-        w9_tile<MT, RELU, false>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0);
+        w9_tile<MT, RELU, false, FIRST>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0, s_first, C0);
 }
 
 static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
-                     int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream, int cob_width) {
+                     int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream, int cob_width,
+                     const float* w1 = nullptr, const float* b1 = nullptr, int C0 = 0, float amax_gain = 1.f, float amax_offs = 0.f) {
     AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
     AC_REQUIRE(B > 0 && C_in > 0 && C_in % 16 == 0 && C_out > 0 && C_out % cob_width == 0, "C_in % 16 == 0 and C_out % (96 or 48) == 0");
     AC_REQUIRE(H > 0 && H % W9_TH == 0 && W > 0 && W % W9_TW == 0, "H % 8 == 0 and W % 32 == 0");
@@ -277,13 +314,17 @@ static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const fl
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
     const f16x8* wp = (const f16x8*)w_packed;
-    if (cob_width == 96) {
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<6, 2, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
+#define W9_GO(MT_, OCC_, RELU_, FIRST_) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<MT_, OCC_, RELU_, FIRST_>), grid, block, 0, st, x, wp, bias, out, \
+        C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax, w1, b1, C0, amax_gain, amax_offs)
+    if (w1) {
+        AC_REQUIRE(b1 && C0 >= 1 && C0 <= 4 && C_in <= 64 && cob_width == 48, "fused first conv: 1 <= C0 <= 4, C_in <= 64, 48-channel workgroups");
+        if (relu) W9_GO(3, W9_FIRST_OCC, true, true); else W9_GO(3, W9_FIRST_OCC, false, true);
+    } else if (cob_width == 96) {
+        if (relu) W9_GO(6, 2, true, false); else W9_GO(6, 2, false, false);
     } else {
-        if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, true>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
-        else      hipLaunchKernelGGL((k_conv3x3_f16x3_w96<3, 3, false>), grid, block, 0, st, x, wp, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
+        if (relu) W9_GO(3, 3, true, false); else W9_GO(3, 3, false, false);
     }
+#undef W9_GO
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -298,4 +339,16 @@ extern "C" int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_pa
                                     int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax,
                                     void* stream) {
     return w9_launch(ctx, x, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, in_amax, out_amax, stream, 48);
+}
+
+// relu(conv3x3(relu(conv1x1(spec, w1) + b1))): the graph's first two convolutions in one launch (see FIRST above).  w_packed is the
+// 3x3 conv's weights in the 48-channel layout of ac_conv3x3_f16x3_s8 (conv_pack.pack_conv3x3_w96(w, 48)).
+extern "C" int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,
+                                       const float* bias, float* out, int B, int C0, int C_in, int C_out, int H, int W,
+                                       float w_unscale, int relu, const float* spec_amax, float amax_gain, float amax_offs,
+                                       float* out_amax, void* stream) {
+    AC_REQUIRE(w1 && b1, "null pointer");
+    AC_REQUIRE(amax_gain >= 0.f && amax_offs >= 0.f, "amax bound terms must be non-negative");
+    return w9_launch(ctx, spec, w_packed, bias, out, B, C_in, C_out, H, W, w_unscale, relu, spec_amax, out_amax, stream, 48, w1, b1, C0,
+                     spec_amax ? amax_gain : 1.f, spec_amax ? amax_offs : 0.f);
 }

@@ -145,10 +145,10 @@ class _Block(nn.Module):
             self.register_buffer(f"lb{j}", torch.from_numpy(sh.astype(np.float32)).view(1, -1, 1, 1))
 
     def pack_for_hip(self) -> None:
-        """Kernel-ready copies of the folded weights: f16 hi/lo MFMA fragments for the 3x3 convs (ac_conv3x3_f16x3 for the fused
-        first conv, ac_conv3x3_f16x3_w96 / _s8 elsewhere) and for the wide TDF layers (ac_tdf_linear_f16x3); float32 fragments
+        """Kernel-ready copies of the folded weights: f16 hi/lo MFMA fragments for the 3x3 convs (ac_conv3x3_f16x3_w96 / _s8,
+        ac_conv3x3_f16x3_first for the fused first one) and for the wide TDF layers (ac_tdf_linear_f16x3); float32 fragments
         for the narrow TDF pairs of the deep levels (ac_tdf_small_fused)."""
-        from .conv_pack import conv3x3_wide_tileable, pack_conv3x3, pack_conv3x3_w96, pack_linear, pack_tdf_small
+        from .conv_pack import conv3x3_wide_tileable, pack_conv3x3_w96, pack_linear, pack_tdf_small
         w0 = self.lw0.detach().cpu().numpy(); w1 = self.lw1.detach().cpu().numpy()
         dev = self.lw0.device
         self._l_unscale = [None, None]
@@ -167,18 +167,15 @@ class _Block(nn.Module):
             if w.shape[0] % 48 or w.shape[1] % 16:
                 self._w_unscale.append(None)
                 continue
-            packed, unscale = pack_conv3x3(w)
-            self._w_unscale.append(unscale)
-            if j == 0:      # only a block's first conv can be the graph's first 3x3 conv (fused with the 1x1 in front of it)
-                self.register_buffer("cwp0", torch.from_numpy(packed.view(np.int16)).to(dev))
-            # the 8-channel-stage kernels (same power-of-two scale: `unscale` holds for every layout): 96 output channels per
-            # workgroup where the shape allows, else 48 with three workgroups per CU
+            # 96 output channels per workgroup where the shape allows, else 48 with three workgroups per CU (the graph's first 3x3
+            # conv, fused with the 1x1 in front of it, takes the 48-channel layout of its block's conv 0)
             if conv3x3_wide_tileable(w.shape[0], w.shape[1]):
-                wide, _ = pack_conv3x3_w96(w, 96)
+                wide, unscale = pack_conv3x3_w96(w, 96)
                 self.register_buffer(f"cwq{j}", torch.from_numpy(wide.view(np.int16)).to(dev))
             else:
-                narrow, _ = pack_conv3x3_w96(w, 48)
+                narrow, unscale = pack_conv3x3_w96(w, 48)
                 self.register_buffer(f"cws{j}", torch.from_numpy(narrow.view(np.int16)).to(dev))
+            self._w_unscale.append(unscale)
 
     def _conv(self, x: torch.Tensor, ax: torch.Tensor, j: int, hip, tape: _AmaxTape, probe):
         """3x3 conv + bias + ReLU: one fused kernel on the f16 matrix cores (3-term hi/lo split, float32-class accuracy)."""
@@ -230,7 +227,10 @@ class _Block(nn.Module):
                 e0.record()
             spec = x
             ay = tape.new(x.shape[2])
-            x = hip.conv3x3_f16x3_first(spec, first[0], first[1], self.cwp0, self.cb0, self.cw0.shape[0], self._w_unscale[0], relu=True,
+            if not hasattr(self, "cws0"):
+                from .._native import NativeError
+                raise NativeError("the fused first conv needs a 48-output-channel-tileable 3x3 conv behind the 1x1 (ac_conv3x3_f16x3_first)")
+            x = hip.conv3x3_f16x3_first(spec, first[0], first[1], self.cws0, self.cb0, self.cw0.shape[0], self._w_unscale[0], relu=True,
                                         spec_amax=ax, amax_gain=first[2], amax_offs=first[3], out_amax=ay)
             ax = ay
             if probe is not None:
@@ -331,7 +331,7 @@ class TfcTdfNet(nn.Module):
                               "(tests/unet_torch.py holds the PyTorch reference evaluation)")
         n = self.spec.n_levels
         b, c0, t, f = spec_tf.shape
-        if not spec_tf.is_contiguous() or c0 > 4 or self.first_w.shape[0] > 64 or t % 8 or f % 32 or not hasattr(self.enc[0], "cwp0"):
+        if not spec_tf.is_contiguous() or c0 > 4 or self.first_w.shape[0] > 64 or t % 8 or f % 32 or not hasattr(self.enc[0], "cws0"):
             raise NativeError(f"spectrogram of shape {tuple(spec_tf.shape)} is not tileable by ac_conv3x3_f16x3_first")
         if spec_amax is None:
             spec_amax = spec_tf.abs().amax(dim=(1, 3)).view(b, t // AMAX_ROWS, AMAX_ROWS).amax(dim=2).contiguous()

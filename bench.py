@@ -143,7 +143,7 @@ class SocketSampler:
         return out
 
 
-DOMINANT = "k_conv3x3_f16x3"           # audio_cut_amd/csrc/ac_conv.hip; rocprofv3 prints it as `void k_conv3x3_f16x3<true>(...)`
+DOMINANT = "k_conv3x3_f16x3"           # audio_cut_amd/csrc/ac_conv96.hip: k_conv3x3_f16x3_w96<MT, OCC, RELU, FIRST>
 F16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_16x16x32_f16)
 # MFMA FLOPs the split issues per algorithmic FLOP: 3 products (hi*hi + hi*lo + lo*hi); tap 8 of two consecutive 16-channel
 # blocks shares one k-step, so only a trailing unpaired block (C/16 odd: C = 48, 144, 240) pads - 1.5 % FLOP-weighted over the U-Net

@@ -29,7 +29,7 @@ extern "C" {
 #define AC_E_HIP (-2)       /* a HIP runtime call failed */
 #define AC_E_NOMEM (-3)
 
-#define AC_ABI_VERSION 2
+#define AC_ABI_VERSION 3
 
 typedef struct ac_ctx ac_ctx;
 
@@ -293,9 +293,10 @@ int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, c
  * 0x7FFFFF / 0x800000 (pcm.c f2let_clip_array).  out [3 * n] bytes. */
 int ac_pack_pcm24(ac_ctx* ctx, const float* x, int64_t n, unsigned char* out, void* stream);
 
-/* ac_conv3x3_f16x3 with the graph's first 1x1 convolution (spec [B][C0][H][W], C0 <= 4, w1 [C_in][C0], b1 [C_in], + ReLU;
- * the first Conv + BatchNormalization + Relu nodes at separation/backends.py:358) fused into its loader: the C_in-channel
- * tensor is generated per staged pixel with ac_conv1x1_small's arithmetic (bit-identical) and never written to HBM.
+/* ac_conv3x3_f16x3_s8 (w_packed in its 48-channel layout: conv_pack.pack_conv3x3_w96(w, 48); C_in <= 64) with the graph's first
+ * 1x1 convolution (spec [B][C0][H][W], C0 <= 4, w1 [C_in][C0], b1 [C_in], + ReLU; the first Conv + BatchNormalization + Relu
+ * nodes at separation/backends.py:358) fused into its loader: a thread's spectrogram float4s are loaded once and the
+ * C_in-channel tensor is generated per staged pixel with ac_conv1x1_small's arithmetic (bit-identical), never written to HBM.
  * spec_amax [B][H] = max |spec| per item and row (ac_mdx_stft); the generated tensor's maximum is bounded by
  * spec_amax * amax_gain + amax_offs with amax_gain = max_c sum_j |w1[c][j]|, amax_offs = max_c |b1[c]| (host constants). */
 int ac_conv3x3_f16x3_first(ac_ctx* ctx, const float* spec, const float* w1, const float* b1, const void* w_packed,

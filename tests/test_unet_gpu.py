@@ -191,28 +191,29 @@ def test_conv1x1_small_kernel(hip_ctx):
 
 
 def test_first_conv_fused_into_the_3x3_loader_is_bit_identical(hip_ctx):
-    """ac_conv3x3_f16x3_first == ac_conv1x1_small followed by ac_conv3x3_f16x3, bit for bit (same float32 FMA order for the
-    generated channels, same zero padding of the conv input), and the whole net is unchanged by the fusion."""
-    from audio_cut_amd.separation.conv_pack import pack_conv3x3
+    """ac_conv3x3_f16x3_first == ac_conv1x1_small followed by ac_conv3x3_f16x3_s8, bit for bit (same float32 FMA order for the
+    generated channels, same zero padding of the conv input, the same kernel behind both), and the whole net is unchanged by the
+    fusion."""
+    from audio_cut_amd.separation.conv_pack import pack_conv3x3_w96
     g = torch.Generator().manual_seed(8)
     dev = hip_ctx.device
     spec = (torch.randn(2, 4, 16, 64, generator=g) * 3).to(dev)
     w1 = (torch.randn(48, 4, 1, 1, generator=g) * 0.5).to(dev); b1 = (torch.randn(48, generator=g) * 0.3).to(dev)
     w3 = torch.randn(48, 48, 3, 3, generator=g) / np.sqrt(9 * 48); b3 = (torch.randn(48, generator=g) * 0.1).to(dev)
-    packed, un = pack_conv3x3(w3.numpy())
+    packed, un = pack_conv3x3_w96(w3.numpy(), 48)
     wp = torch.from_numpy(packed.view(np.int16)).to(dev)
     mid = hip_ctx.conv1x1_small(spec, w1, b1, relu=True)
-    ref = hip_ctx.conv3x3_f16x3(mid, wp, b3, 48, un, relu=True)
+    ref = hip_ctx.conv3x3_f16x3_s8(mid, wp, b3, 48, un, relu=True)
     got = hip_ctx.conv3x3_f16x3_first(spec, w1, b1, wp, b3, 48, un, relu=True)
     assert torch.equal(got, ref)
-    # with the per-item activation scale: the fused kernel scales by the BOUND of the generated tensor, the unfused pair by its
+    # with the per-row activation scale: the fused kernel scales by the BOUND of the generated tensor, the unfused pair by its
     # measured maximum - the same values up to the float16 low parts' last bit
     amax_spec = _blk_amax(spec)
     gain = float(w1.abs().sum(dim=(1, 2, 3)).max()); offs = float(b1.abs().max())
     oa = torch.zeros((2, 16), device=dev)
     got2 = hip_ctx.conv3x3_f16x3_first(spec, w1, b1, wp, b3, 48, un, relu=True, spec_amax=amax_spec, amax_gain=gain, amax_offs=offs, out_amax=oa)
     assert bool((_blk_amax(mid) <= amax_spec * gain + offs).all())
-    ref2 = hip_ctx.conv3x3_f16x3(mid, wp, b3, 48, un, relu=True, in_amax=_blk_amax(mid))
+    ref2 = hip_ctx.conv3x3_f16x3_s8(mid, wp, b3, 48, un, relu=True, in_amax=_blk_amax(mid))
     assert float((got2 - ref2).abs().max() / ref2.abs().max()) < 1e-6
     assert torch.equal(oa, _blk_amax(got2))
     # a burst's leakage into digital silence (rows falling by 1e-3 each, then exact zeros), bias-free like the synthetic net: the
