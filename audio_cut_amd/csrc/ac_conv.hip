@@ -48,7 +48,6 @@ __device__ inline unsigned short f16_bits(_Float16 h) { return __builtin_bit_cas
 __device__ inline int cv_phys(int c) { return c ^ (((c >> 2) & 1) << 1); } // staged column of logical column c (0..39)
 #define CV_WFRAGS (5 * 2 * CV_MT * 64)                                     // 1920 16-byte weight fragments per stage
 #define CV_WFRAGS_PAIRS (4 * 2 * CV_MT * 64)                               // 1536: the four in-block tap pairs
-#define CV_W_ITERS ((CV_WFRAGS + 255) / 256)                               // 8
 #define CV_OUT_STRIDE (CV_TW + 4)                                          // floats per (co, row) line of the output staging
 
 template <bool RELU>
@@ -57,16 +56,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                                                           int C_in, int C_out, int H, int W, float w_unscale, int bw,
                                                           const float* __restrict__ in_amax, float* __restrict__ out_amax) {
     // one LDS arena: [hi patch | lo patch | weight fragments] during the K loop, re-used as the output staging tile
-    // The plain kernel (DMA) double-buffers the weight fragments - even stages (4 k-steps) in one buffer, odd stages (5) in
-    // the other - and fills them with global_load_lds (no registers, issued a stage ahead): 25,600 + 24,576 + 30,720 =
-    // 80,896 B, two workgroups per CU still fit the 160 KB.
-    constexpr bool DMA = true;
+    // The weight fragments are double-buffered - even stages (4 k-steps) in one buffer, odd stages (5) in the other - and filled
+    // with global_load_lds (no registers, issued a stage ahead): 25,600 + 24,576 + 30,720 = 80,896 B, two workgroups per CU
+    // still fit the 160 KB.
     constexpr int PATCH_BYTES = 2 * CV_PH * CV_LW * CV_PIX_STRIDE * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[PATCH_BYTES + (DMA ? (CV_WFRAGS_PAIRS + CV_WFRAGS) : CV_WFRAGS) * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[PATCH_BYTES + (CV_WFRAGS_PAIRS + CV_WFRAGS) * 16];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + CV_PH * CV_LW * CV_PIX_STRIDE;
     f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw + PATCH_BYTES);            // even stages
-    f16x8* s_w1 = DMA ? s_w0 + CV_WFRAGS_PAIRS : s_w0;                         // odd stages
+    f16x8* s_w1 = s_w0 + CV_WFRAGS_PAIRS;                                      // odd stages
     float* s_out = reinterpret_cast<float*>(s_raw);       // [48 co][8 rows][CV_OUT_STRIDE] = 55296 B <= arena (56320 B)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_cob = C_out / CV_COB;
@@ -142,25 +140,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         }
     }
     float4 pre_x[CV_ACT_ITERS][4];
-    f16x8 pre_w[CV_W_ITERS];
     auto prefetch = [&](int cb) {
         const f16x8* wcb = wbase + (size_t)cb * CV_WFRAGS;
-        if (DMA) {
-            // weight fragments are already in LDS order: each wave-instruction copies 64 of them (1 KB) straight into the buffer
-            f16x8* dst = (cb & 1) ? s_w1 : s_w0;
-            const int n_inst = (cb & 1) ? CV_WFRAGS / 64 : CV_WFRAGS_PAIRS / 64;        // 30 or 24 (an even stage keeps 4 k-steps in LDS)
+        // weight fragments are already in LDS order: each wave-instruction copies 64 of them (1 KB) straight into the buffer
+        f16x8* dst = (cb & 1) ? s_w1 : s_w0;
+        const int n_inst = (cb & 1) ? CV_WFRAGS / 64 : CV_WFRAGS_PAIRS / 64;            // 30 or 24 (an even stage keeps 4 k-steps in LDS)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int inst = wave + 4 * i;
-                if (inst < n_inst) __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
-            }
-        } else {
-            const int nfr = (!(cb & 1) && cb + 1 < n_cb) ? CV_WFRAGS_PAIRS : CV_WFRAGS;     // an even block with a partner has no fifth k-step
-#pragma unroll
-            for (int i = 0; i < CV_W_ITERS; ++i) {
-                const int e = tid + 256 * i;
-                if (e < nfr) pre_w[i] = wcb[e];
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int inst = wave + 4 * i;
+            if (inst < n_inst) __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
@@ -173,13 +161,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         }
     };
 
-    // DMA kernel, C_in / 16 odd: the last stage has no partner and its buffer holds four k-steps only, so every lane keeps its
+    // C_in / 16 odd: the last stage has no partner and its buffer holds four k-steps only, so every lane keeps its
     // own fragments of that stage's tap-8 step in registers from the start (they are per-lane data: LDS is only a broadcast)
     f16x8 tail_h[CV_MT], tail_l[CV_MT];
 #pragma unroll
     for (int m = 0; m < CV_MT; ++m) {
         tail_h[m] = (f16x8)(_Float16)0; tail_l[m] = (f16x8)(_Float16)0;
-        if (DMA && (n_cb & 1)) {
+        if (n_cb & 1) {
             const f16x8* wlast = wbase + (size_t)(n_cb - 1) * CV_WFRAGS;
             tail_h[m] = wlast[((4 * 2 + 0) * CV_MT + m) * 64 + lane];
             tail_l[m] = wlast[((4 * 2 + 1) * CV_MT + m) * 64 + lane];
@@ -190,14 +178,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
         __syncthreads();                 // previous stage fully consumed
         const bool odd = cb & 1;
         const bool shared_step = odd || cb + 1 >= n_cb;      // this block issues the tap-8 k-step (its own half, or both halves)
-        if (!DMA) {
-            const int nfr = shared_step ? CV_WFRAGS : CV_WFRAGS_PAIRS;
-#pragma unroll
-            for (int i = 0; i < CV_W_ITERS; ++i) {
-                const int e = tid + 256 * i;
-                if (e < nfr) s_w0[e] = pre_w[i];
-            }
-        }
         const f16x8* s_w = (cb & 1) ? s_w1 : s_w0;
 #pragma unroll
         for (int i = 0; i < CV_ACT_ITERS; ++i) {
@@ -223,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
                 *reinterpret_cast<uint2*>(&s_lo[off]) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
             }
         }
-        if (DMA) __builtin_amdgcn_s_waitcnt(0);            // this stage's weight fragments have landed (issued before the x loads just consumed)
+        __builtin_amdgcn_s_waitcnt(0);            // this stage's weight fragments have landed (issued before the x loads just consumed)
         __syncthreads();
         if (cb + 1 < n_cb) prefetch(cb + 1);   // global loads of the next stage fly under this stage's MFMAs
 #pragma unroll
@@ -267,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3(const float* __restric
             f16x8 ah[CV_MT], al[CV_MT];
 #pragma unroll
             for (int m = 0; m < CV_MT; ++m) {
-                if (DMA && !odd) {       // trailing unpaired stage: its fifth k-step is not in LDS (fetched per lane before the loop)
+                if (!odd) {       // trailing unpaired stage: its fifth k-step is not in LDS (fetched per lane before the loop)
                     ah[m] = tail_h[m];
                     al[m] = tail_l[m];
                 } else {
