@@ -28,6 +28,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define W9_CB 8                  // input channels per stage
 #define W9_PATCH_BYTES (2 * W9_PH * W9_RS * W9_CB * 2)
 #define W9_OUT_STRIDE (W9_TW + 4)
+#ifndef W9_VARIANT
+#define W9_VARIANT 0                 // 1 / 2: probe builds of tools/sharing_probe_variants.py, never the product
+#endif
 #ifndef W9_FIRST_OCC
 #define W9_FIRST_OCC 3               // workgroups per CU of the fused first conv
 #endif
@@ -48,10 +51,17 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     constexpr int W9_MT = MT, W9_COB = 16 * MT;
     constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
     constexpr int EP_M = (MT == 6) ? 3 : 2;                   // row tiles per epilogue pass (the output tile must fit the arena)
+#if W9_VARIANT == 1                   // probe build (tools/sharing_probe_variants.py): weight buffers first, so every LDS-DMA lands 1 KiB aligned
+    f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw);
+    f16x8* s_w1 = s_w0 + 2 * W9_KFR;
+    unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw + 5 * W9_KFR * 16);
+    unsigned short* s_lo = s_hi + W9_PH * W9_RS * W9_CB;
+#else
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + W9_PH * W9_RS * W9_CB;
     f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw + W9_PATCH_BYTES);           // even stages: 2 k-steps
     f16x8* s_w1 = s_w0 + 2 * W9_KFR;                                           // odd stages: 2 k-steps (+ the shared tap-8 step)
+#endif
     float* s_out = reinterpret_cast<float*>(s_raw);                           // [16 EP_M co][8 rows][36], MT / EP_M passes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, px = lane & 15;
@@ -109,7 +119,11 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int inst = wave + 4 * i;
+#if W9_VARIANT == 2                   // probe build: no LDS-DMA - the fragments go through registers (slow; an aggressor only)
+            if (inst < n_inst) dst[inst * 64 + lane] = wcb[inst * 64 + lane];
+#else
             if (inst < n_inst) __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
+#endif
         }
     };
 

@@ -111,6 +111,44 @@ def detect_and_finalize(mix: np.ndarray, vocal: np.ndarray, sr: int, cache: Opti
     return pauses, cands, bounds
 
 
+def finalize_vpbd(mix: np.ndarray, vocal: np.ndarray, sr: int, cache: Optional[FT.FeatureCache], markers: Optional[Dict],
+                  selected: Sequence[Tuple[float, float]], suppressed_by_planner: Sequence[Tuple[float, float]],
+                  policy_out: Optional[list] = None) -> List[int]:
+    """seamless_splitter.py:362-408,436-520 for mode vpbd_acoustic: the candidates are the VPBD planner's selection
+    (`selected`: (t, score); the planner's positive-score suppressed ones as the rescue set when nothing was selected,
+    `:396-401`) instead of the pauses; then the same no-vocal runs, presence markers, guard and boundary policy as v2.2_mdd."""
+    cands: List[Tuple[float, float]] = [(float(t), float(s)) for t, s in selected]
+    if not cands:
+        cands = [(float(t), float(s)) for t, s in suppressed_by_planner if float(s) > 0.0]
+    if not cands:
+        return [0, len(mix)]
+    min_music = float(get_config("quality_control.pure_music_min_duration", 0.0))
+    if min_music > 0.0:
+        for a, b in D.no_vocal_runs(vocal, sr, min_music):
+            cands.append((float(a), 1.0)); cands.append((float(b), 1.0))
+    dur = len(mix) / sr
+    protected = set()
+    for t in (markers or {}).get("vocal_presence_cut_points_sec", []):
+        if 0.0 < t < dur:
+            cands.append((float(t), 1.0))
+            protected.add(int(round(t * sr)))
+    refined = finalize_and_filter_cuts(cands, mix, vocal, sr)
+    suppressed = [(float(c.t), float(c.score)) for c in (refined.suppressed or [])]
+    bounds = set(refined.sample_boundaries)
+    for s in protected:
+        s = int(min(max(s, 0), len(mix)))
+        if s not in (0, len(mix)):
+            bounds.add(s)
+    bounds = sorted(bounds)
+    if policy_out is not None:
+        from . import layout as LY
+        policy_out.append(LY.apply_boundary_policy(bounds, vocal, len(mix), sr, suppressed=suppressed,
+                                                   rms_series=None if cache is None else cache.rms_series,
+                                                   hop_s=0.05 if cache is None else cache.hop_s,
+                                                   beat_times=None if cache is None else cache.beat_times))
+    return bounds
+
+
 def run_track(mix: np.ndarray, sr: int, weights, *, vad_fn=None, n_levels: int = 5, l: int = 3) -> TrackResult:
     """Full oracle path for one track (needs torch for the CPU U-Net)."""
     from . import separator as S

@@ -13,9 +13,7 @@ from typing import Dict
 import numpy as np
 
 
-def synth_silero_weights(seed: int = 0, calib: str = "voice") -> Dict[str, np.ndarray]:
-    from audio_cut_amd.testing import signals
-    from oracle import silero as OS
+def _base_weights(seed: int) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     w: Dict[str, np.ndarray] = {}
     n = np.arange(256)
@@ -34,9 +32,26 @@ def synth_silero_weights(seed: int = 0, calib: str = "voice") -> Dict[str, np.nd
     w["decoder.rnn.bias_hh"] = (rng.standard_normal(512) * 0.05).astype(np.float32)
     w["decoder.decoder.2.weight"] = (rng.standard_normal((1, 128, 1)) / np.sqrt(128)).astype(np.float32)
     w["decoder.decoder.2.bias"] = np.zeros(1, np.float32)
-    # calibrate the output layer: logit -> a * logit + b
-    # "voice": a sung line at its natural level; "bursts": tone bursts / exact silences at the level a separated stem has
-    clip44 = signals.voice_with_rests(12.0, seed=1000 + seed) if calib == "voice" else 0.35 * signals.c1_sine_silence(12.0, seed=1000 + seed)
+    return w
+
+
+def calibration_affine(seed: int = 0, calib: str = "voice"):
+    """(a, b) of the output layer's calibration logit -> a * logit + b, fitted with the CPU oracle on a seeded clip.
+    "voice": a sung line at its natural level; "bursts": tone bursts / exact silences at the level a separated stem has;
+    "c2_stem": what the chunked VAD actually sees on the C2 / C4 track - the CPU oracle's vocal stem (synthetic U-Net weights
+    seed 0) of the first 20 s of the C2 song (seed 2): a quiet, fairly even signal on which the other two calibrations find no
+    speech at all (profiles/r02_parity_soak_h.log: vad_segments=0 on every song)."""
+    from audio_cut_amd.testing import signals
+    from oracle import silero as OS
+    w = _base_weights(seed)
+    if calib == "c2_stem":
+        from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+        from oracle import separator as OSEP
+        mix = signals.c2_song(20.0, seed=2)
+        mix = np.mean(mix, axis=0).astype(np.float32) if mix.ndim == 2 else mix
+        clip44 = OSEP.separate_track(mix, 44100, synth_weights(TfcTdfSpec(), seed=0))[0]
+    else:
+        clip44 = signals.voice_with_rests(12.0, seed=1000 + seed) if calib == "voice" else 0.35 * signals.c1_sine_silence(12.0, seed=1000 + seed)
     clip = OS.resample_to_16k(clip44, 44100)
     p = OS.silero_probs(w, clip).astype(np.float64)
     logit = np.log(np.clip(p, 1e-7, 1 - 1e-7) / np.clip(1 - p, 1e-7, 1))
@@ -46,6 +61,14 @@ def synth_silero_weights(seed: int = 0, calib: str = "voice") -> Dict[str, np.nd
     sign = 1.0 if np.corrcoef(logit, energy)[0, 1] >= 0 else -1.0
     a = sign * 5.0 / max(hi - lo, 1e-3)
     b = -a * 0.5 * (hi + lo)
-    w["decoder.decoder.2.weight"] = (w["decoder.decoder.2.weight"] * a).astype(np.float32)
+    return float(a), float(b)
+
+
+def synth_silero_weights(seed: int = 0, calib: str = "voice", affine=None) -> Dict[str, np.ndarray]:
+    """`affine` = (a, b) of an earlier `calibration_affine` (a fixture stores it): the output layer is set from it and the CPU
+    oracle is not needed - this is how bench.py's C4 leg gets its VAD weights without importing anything under oracle/."""
+    w = _base_weights(seed)
+    a, b = (float(affine[0]), float(affine[1])) if affine is not None else calibration_affine(seed, calib)
+    w["decoder.decoder.2.weight"] = (w["decoder.decoder.2.weight"].astype(np.float64) * np.float64(a)).astype(np.float32)   # float64 product, rounded once
     w["decoder.decoder.2.bias"] = np.asarray([b], dtype=np.float32)
     return w

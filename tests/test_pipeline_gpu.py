@@ -593,3 +593,54 @@ def test_build_feature_cache_whole_track_variant(hip_ctx):
     assert np.array_equal(again.rms_series, cache.rms_series) and np.array_equal(again.beat_times, cache.beat_times)
     with pytest.raises(ValueError):
         build_feature_cache(np.zeros(0, np.float32), None, SR, ctx=hip_ctx)
+
+
+def _run_with_silero(hip_ctx, tmp_path, mix, weight_seed, silero_seed, calib, mode="v2.2_mdd"):
+    """The product path with the Silero network as the chunked VAD (synthetic weights file configured)."""
+    from audio_cut_amd import config as C
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
+    from audio_cut_amd.detectors.silero_vad import SileroHipVad
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
+    from silero_synth import synth_silero_weights
+    np.savez(tmp_path / "silero.npz", **synth_silero_weights(silero_seed, calib=calib))
+    backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=weight_seed), ctx=hip_ctx, max_items_per_forward=32)
+    backend.load_model()
+    saved = C.snapshot()
+    try:
+        C.set_runtime_config({"advanced_vad.silero_weights_path": str(tmp_path / "silero.npz")})
+        sep = EnhancedVocalSeparator(SR, backend=backend)
+        res = SeamlessSplitter(SR, separator=sep).split_track(mix, mode=mode)
+        assert isinstance(sep._vad_inference_fn, SileroHipVad)
+    finally:
+        C.restore(saved)
+    return res
+
+
+def test_soak_track_on_the_epsilon_plateau_is_exact_or_plateau_equivalent(hip_ctx, golden_dir, tmp_path):
+    """The one round-2 live-soak track (of 33) whose guard boundary was not the oracle's: c1_sine_silence 60 s, song seed 301,
+    U-Net weights 61, Silero weights 1 (`profiles/r02_parity_soak_g_silero.log`: 2407370 vs 2407367).  Every interior boundary of
+    this track sits in digital silence, on the epsilon plateau of the guard's dB series (tests/guard_plateau.py), where the
+    reference's `np.argmin` lands on the sample at which float32 inverse-FFT rounding noise leaves the 80 ms window.
+    Asserted: everything upstream exact (VAD segments, pause cut points); every boundary either EQUAL or - only on the plateau -
+    at an index where the oracle's own vocal and mix dB series are bit-equal to their values at the oracle's index, with the
+    stem around it within 1e-5 of the peak; manifest cuts equal after that mapping.  This is an equivalence class, not a sample
+    tolerance: off the plateau nothing may move."""
+    from guard_plateau import classify_boundaries, map_cuts
+    g = np.load(golden_dir / "c1_60s_seed301_w61_silero1_oracle.npz")
+    assert int(g["on_plateau"].sum()) == 14                      # all interior boundaries of this track are plateau decisions
+    mix = signals.c1_sine_silence(60.0, seed=301)
+    res = _run_with_silero(hip_ctx, tmp_path, mix, weight_seed=61, silero_seed=1, calib="bursts")
+    assert np.array_equal(np.asarray([[s["start"], s["end"]] for s in res["vad_segments"]], dtype=np.float64).reshape(-1, 2), g["vad_segments"])
+    assert np.array_equal(np.asarray([p.cut_point for p in res["pauses"]]), g["pause_cut_points"])
+    peak = float(g["vocal_peak"])
+    stem_err = float(np.max(np.abs(res["vocal_track"][: 4 * SR: 7] - g["vocal_head"]))) / peak
+    ctx = {k: g[k] for k in ("on_plateau", "db_vocal", "db_mix", "stem_window", "guard_half_window")}
+    exact, equiv, fails = classify_boundaries(res["sample_boundaries"], g["sample_boundaries"].tolist(), ctx, res["vocal_track"], stem_atol=1e-5 * peak)
+    print(f"seed 301 / w61 / silero 1: stem error {stem_err:.2e} of peak; {len(exact)} boundaries exact, plateau-equivalent (gpu, oracle): {equiv}")
+    assert not fails, fails
+    assert len(equiv) <= 2, equiv            # round 2 measured one (3 samples); a second one would be news worth reading, not a pass
+    assert map_cuts(res["cuts_samples"], equiv) == g["cuts"].tolist()
+    assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
+    assert stem_err < 5e-6
