@@ -28,14 +28,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define W9_CB 8                  // input channels per stage
 #define W9_PATCH_BYTES (2 * W9_PH * W9_RS * W9_CB * 2)
 #define W9_OUT_STRIDE (W9_TW + 4)
-#ifndef W9_VARIANT
-#define W9_VARIANT 0                 // 1 / 2: probe builds of tools/sharing_probe_variants.py, never the product
-#endif
+#ifndef W9_PROBE
+#define W9_PROBE 0                   // bit mask of ablations for the probe builds of tools/sharing_probe_*.py (never the product):
+#endif                               // 1 weights first in LDS, 2 no LDS-DMA, 4 no MFMA, 8 no activation staging, 0x10 no shared tap-8 step,
+                                     // 0x20 no epilogue, 0x40 no K loop, 0x80 no activation loads
 #ifndef W9_FIRST_OCC
 #define W9_FIRST_OCC 3               // workgroups per CU of the fused first conv
 #endif
 
 __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+
+#if W9_PROBE & 4                      // probe build: the operands stay live, the matrix instruction is not issued
+__device__ __forceinline__ f32x4 w9_mfma(f16x8 a, f16x8 b, f32x4 c) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+#else
+__device__ __forceinline__ f32x4 w9_mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#endif
 
 // MT = 16-row output-channel tiles per workgroup: 6 (96 channels, two workgroups per CU) or 3 (48 channels, three per CU).
 // ROWX: the row-exact path of ac_common.h (per-row staging scales, power-of-two fragment factors); s_ex = log2 scale per patch row.
@@ -51,7 +58,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     constexpr int W9_MT = MT, W9_COB = 16 * MT;
     constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
     constexpr int EP_M = (MT == 6) ? 3 : 2;                   // row tiles per epilogue pass (the output tile must fit the arena)
-#if W9_VARIANT == 1                   // probe build (tools/sharing_probe_variants.py): weight buffers first, so every LDS-DMA lands 1 KiB aligned
+#if W9_PROBE & 1                      // probe build: weight buffers first, so every LDS-DMA lands 1 KiB aligned
     f16x8* s_w0 = reinterpret_cast<f16x8*>(s_raw);
     f16x8* s_w1 = s_w0 + 2 * W9_KFR;
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw + 5 * W9_KFR * 16);
@@ -108,7 +115,11 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ci = FIRST ? q : cb * W9_CB + a_c4 * 4 + q;               // FIRST: the spectrogram's channels, fetched once
+#if W9_PROBE & 0x80
+            pxr[q] = make_float4(1.f + ci, 2.f, 3.f, 4.f);
+#else
             pxr[q] = (!FIRST || q < C0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
     };
     auto prefetch_w = [&](int cb) {
@@ -119,7 +130,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int inst = wave + 4 * i;
-#if W9_VARIANT == 2                   // probe build: no LDS-DMA - the fragments go through registers (slow; an aggressor only)
+#if W9_PROBE & 2                      // probe build: no LDS-DMA - the fragments go through registers (slow; an aggressor only)
             if (inst < n_inst) dst[inst * 64 + lane] = wcb[inst * 64 + lane];
 #else
             if (inst < n_inst) __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
@@ -128,10 +139,10 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     };
 
     prefetch_w(0); prefetch_x(0, pre_x);
-    for (int cb = 0; cb < n_cb; ++cb) {
+    for (int cb = 0; cb < ((W9_PROBE & 0x40) ? 0 : n_cb); ++cb) {
         float4 (&pxr)[4] = pre_x;
         __syncthreads();                 // previous stage fully consumed
-        if (a_live) {
+        if (a_live && !(W9_PROBE & 8)) {
             const float zs = a_src >= 0 ? act_s : 0.f;         // zero padding (and the idle slots of a row)
             const float* v4[4] = {&pxr[0].x, &pxr[1].x, &pxr[2].x, &pxr[3].x};
             if (FIRST) {
@@ -209,14 +220,14 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
                 const f16x8 al = s_w[((ks * 2 + 1) * W9_MT + m) * 64 + lane];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = w9_mfma(ah, bl[q], acc[m][q]);
+                    acc[m][q] = w9_mfma(al, bh[q], acc[m][q]);
+                    acc[m][q] = w9_mfma(ah, bh[q], acc[m][q]);
                 }
             }
         }
         // tap 8 (dy = dx = 2) of this stage goes into lane group cb & 3 of the carried fragments
-        if (g == (cb & 3)) {
+        if (g == (cb & 3) && !(W9_PROBE & 0x10)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
@@ -226,22 +237,26 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
                 if (ROWX) { const _Float16 f = ac_rowx_frag_factor(s_ex, ty, 2); k8h[q] *= (f16x8)f; k8l[q] *= (f16x8)f; }
             }
         }
-        if ((cb & 3) == 3 || cb == n_cb - 1) {           // a trailing group of two stages: lane groups 2-3 meet zero weights
+        if (((cb & 3) == 3 || cb == n_cb - 1) && !(W9_PROBE & 0x10)) {           // a trailing group of two stages: lane groups 2-3 meet zero weights
 #pragma unroll
             for (int m = 0; m < W9_MT; ++m) {
                 const f16x8 ah = s_w[((2 * 2 + 0) * W9_MT + m) * 64 + lane];
                 const f16x8 al = s_w[((2 * 2 + 1) * W9_MT + m) * 64 + lane];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, k8l[q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, k8h[q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, k8h[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = w9_mfma(ah, k8l[q], acc[m][q]);
+                    acc[m][q] = w9_mfma(al, k8h[q], acc[m][q]);
+                    acc[m][q] = w9_mfma(ah, k8h[q], acc[m][q]);
                 }
             }
         }
     }
     // ---- epilogue in passes of EP_M row tiles through the LDS tile [co][row][x] -> 128-byte row stores
     float vmax[2] = {0.f, 0.f};          // this wave's two output rows (ty = 2 wave + (q >> 1))
+#if W9_PROBE & 0x20
+    if (acc[0][0][0] == 12345.678f) out[0] = acc[0][0][0] + acc[W9_MT - 1][3][3];      // probe build: no epilogue (the accumulators stay live)
+    return;
+#endif
 #pragma unroll
     for (int m0 = 0; m0 < W9_MT; m0 += EP_M) {
         const int n_m = (W9_MT - m0) < EP_M ? (W9_MT - m0) : EP_M;

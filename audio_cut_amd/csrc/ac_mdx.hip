@@ -17,11 +17,35 @@
 
 __device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
+// MDX_NT_LOADS / MDX_PROBE (probe builds of tools/sharing_probe_*.py only): every global load of the FFT kernels bypasses the
+// CU's vector L1 (`nt`: served by L2) / bit 2: the butterflies run without their twiddle factors (no table loads in the passes)
+#ifndef MDX_NT_LOADS
+#define MDX_NT_LOADS 0
+#endif
+#ifndef MDX_PROBE
+#define MDX_PROBE 0
+#endif
+__device__ inline float mdx_ldf(const float* p) {
+#if MDX_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ inline float2 mdx_ld2(const float2* p) {
+#if MDX_NT_LOADS
+    const unsigned long long u = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+#else
+    return *p;
+#endif
+}
+
 // exp(-2*pi*i*q/3072) from the half-circle table tw[k] = exp(-2*pi*i*k/6144), k < 3072
 __device__ inline float2 tw3072(const float2* __restrict__ tw, int q) {
     int k = 2 * q;                       // 0 .. 6142
-    if (k >= MDX_M) { const float2 t = tw[k - MDX_M]; return make_float2(-t.x, -t.y); }
-    return tw[k];
+    if (k >= MDX_M) { const float2 t = mdx_ld2(tw + (k - MDX_M)); return make_float2(-t.x, -t.y); }
+    return mdx_ld2(tw + k);
 }
 
 // 3072-point complex forward FFT in LDS (256 threads): five radix-4 Stockham passes then one radix-3.
@@ -31,7 +55,7 @@ __device__ float2* fft3072_f32(float2* a, float2* b, const float2* __restrict__ 
         for (int j = threadIdx.x; j < MDX_M / 4; j += 256) {
             const int k = j & (Ns - 1);
             float2 v0 = a[j], v1 = a[j + MDX_M / 4], v2 = a[j + MDX_M / 2], v3 = a[j + 3 * MDX_M / 4];
-            if (Ns > 1) {
+            if (Ns > 1 && !(MDX_PROBE & 2)) {
                 const int q = k * (MDX_M / (4 * Ns));       // exp(-2 pi i k m / (4 Ns)) = W_3072^(q m)
                 v1 = cmulf(v1, tw3072(tw, q));
                 v2 = cmulf(v2, tw3072(tw, 2 * q));
@@ -55,8 +79,10 @@ __device__ float2* fft3072_f32(float2* a, float2* b, const float2* __restrict__ 
         for (int j = threadIdx.x; j < MDX_M / 3; j += 256) {
             const int k = j;                                      // j < Ns = 1024
             float2 v0 = a[j], v1 = a[j + 1024], v2 = a[j + 2048];
-            v1 = cmulf(v1, tw3072(tw, k));                        // exp(-2 pi i k / 3072)
-            v2 = cmulf(v2, tw3072(tw, 2 * k));
+            if (!(MDX_PROBE & 2)) {
+                v1 = cmulf(v1, tw3072(tw, k));                    // exp(-2 pi i k / 3072)
+                v2 = cmulf(v2, tw3072(tw, 2 * k));
+            }
             const float2 s = make_float2(v1.x + v2.x, v1.y + v2.y);
             const float2 d = make_float2(v1.x - v2.x, v1.y - v2.y);
             const float2 m = make_float2(v0.x + c3 * s.x, v0.y + c3 * s.y);
@@ -146,11 +172,11 @@ __global__ __launch_bounds__(256) void k_mdx_istft_frames(const float* __restric
     // Z[k] = E[k] + i O[k];  E = (X[k] + conj X[M-k])/2 ; O = conj(W^k) (X[k] - conj X[M-k])/2 ; load conj(Z) for the
     // inverse-by-forward trick
     for (int k = threadIdx.x; k < MDX_M; k += 256) {
-        float2 xk = make_float2(re_p[k], k == 0 ? 0.f : im_p[k]);
-        float2 xm = (k == 0) ? make_float2(0.f, 0.f) : make_float2(re_p[MDX_M - k], im_p[MDX_M - k]);   // X[M] = 0 (dropped bin)
+        float2 xk = make_float2(mdx_ldf(re_p + k), k == 0 ? 0.f : mdx_ldf(im_p + k));
+        float2 xm = (k == 0) ? make_float2(0.f, 0.f) : make_float2(mdx_ldf(re_p + (MDX_M - k)), mdx_ldf(im_p + (MDX_M - k)));   // X[M] = 0 (dropped bin)
         const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
         const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-        const float2 w = tw[k];
+        const float2 w = mdx_ld2(tw + k);
         const float2 o = cmulf(make_float2(w.x, -w.y), d);       // conj(W^k) * d
         // Z = e + i o = (e.x - o.y, e.y + o.x) ; store conj(Z)
         s_a[k] = make_float2(e.x - o.y, -(e.y + o.x));
@@ -162,7 +188,8 @@ __global__ __launch_bounds__(256) void k_mdx_istft_frames(const float* __restric
     for (int m = threadIdx.x; m < MDX_M; m += 256) {
         const float2 v = z[m];                                   // conj(v)/M = z[m]
         const float x0 = v.x * inv, x1 = -v.y * inv;
-        reinterpret_cast<float2*>(out)[m] = make_float2(x0 * hann[2 * m], x1 * hann[2 * m + 1]);
+        const float2 hw = mdx_ld2(reinterpret_cast<const float2*>(hann) + m);
+        reinterpret_cast<float2*>(out)[m] = make_float2(x0 * hw.x, x1 * hw.y);
     }
 }
 

@@ -306,7 +306,8 @@ static int rs_launch(int mode, ac_ctx* ctx, const float* x, const void* w_packed
     }
     AC_REQUIRE(P % RS_BM == 0, "pixels per image % 128 == 0");
     AC_REQUIRE(mode != 0 || !(in_amax || out_amax) || (W / 2) % 4 == 0, "down with amax: (W / 2) % 4 == 0 (a float4 of outputs stays in one row)");
-    AC_REQUIRE(mode != 1 || !(in_amax || out_amax) || (W >= 64 && W % 2 == 0), "up with amax: W >= 64 and even (a wave's 64 pixels lie in at most two rows)");
+    // the staging thread scales its four consecutive pixels with ONE row's maximum: W % 4 == 0 (required for `up` above) keeps a quad in one row
+    AC_REQUIRE(mode != 1 || !(in_amax || out_amax) || (W >= 64 && W % 4 == 0), "up with amax: W >= 64 and W % 4 == 0 (a staged pixel quad lies in one row, a wave's 64 pixels in at most two)");
     AC_REQUIRE((long long)H * W * 4 < (1LL << 31), "plane too large");
     const int n_stage = (K + RS_BK - 1) / RS_BK, n_nblk = (N + RS_BN - 1) / RS_BN;
     const long long n_mblk = (long long)B * (P / RS_BM);

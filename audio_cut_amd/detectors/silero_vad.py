@@ -125,8 +125,22 @@ class SileroHipVad:
         self.weights = validate_silero_weights(weights)
         self._ctx = ctx
         self._packed: Optional[dict] = None
+        self.adaptive_params: Optional[Dict[str, float]] = None      # see set_adaptive_params
         g = math.gcd(SR16, self.sample_rate)
         self._up, self._down = SR16 // g, self.sample_rate // g
+
+    def set_adaptive_params(self, vad_threshold: Optional[float] = None, min_pause_duration: Optional[float] = None,
+                            speech_pad_ms: Optional[float] = None) -> None:
+        """The reference's adaptive branch (`vocal_pause_detector.py:198-206`): when `current_adaptive_params` is set,
+        `get_speech_timestamps` runs with its `vad_threshold`, `min_pause_duration` (seconds -> min silence) and `speech_pad_ms`
+        instead of the static configuration.  Call with no arguments to go back to the static parameters."""
+        if vad_threshold is None and min_pause_duration is None and speech_pad_ms is None:
+            self.adaptive_params = None
+            return
+        if vad_threshold is None or min_pause_duration is None or speech_pad_ms is None:
+            raise ValueError("adaptive VAD parameters come as a set: vad_threshold, min_pause_duration, speech_pad_ms")
+        self.adaptive_params = {"threshold": float(vad_threshold), "min_silence_ms": float(int(float(min_pause_duration) * 1000)),
+                                "pad_ms": float(int(speech_pad_ms))}
 
     # -- weights in kernel order ------------------------------------------------------------------------
     def _pack(self) -> dict:
@@ -178,12 +192,13 @@ class SileroHipVad:
             if x.numel() == 0:
                 return []
             chunk = self.precompute(x, [0], [int(x.numel())])[0]
+        ap = self.adaptive_params
         stamps = speech_timestamps(
             chunk.probs, chunk.n16_padded, WINDOW, SR16,
-            threshold=float(get_config("advanced_vad.silero_prob_threshold_down", 0.35)),
+            threshold=ap["threshold"] if ap else float(get_config("advanced_vad.silero_prob_threshold_down", 0.35)),
             min_speech_ms=float(get_config("advanced_vad.silero_min_speech_ms", 250)),
-            min_silence_ms=float(get_config("advanced_vad.silero_min_silence_ms", 700)),
-            pad_ms=float(get_config("advanced_vad.silero_speech_pad_ms", 150)))
+            min_silence_ms=ap["min_silence_ms"] if ap else float(get_config("advanced_vad.silero_min_silence_ms", 700)),
+            pad_ms=ap["pad_ms"] if ap else float(get_config("advanced_vad.silero_speech_pad_ms", 150)))
         out: List[Dict[str, int]] = []
         scale = self.sample_rate / SR16
         for ts in stamps:                                                   # vocal_pause_detector.py:268-296

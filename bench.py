@@ -258,12 +258,14 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2",
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2",
                     help="c2: 4-min tracks, K per rank (default; N > 1 deals the C3 seeds); c3: exactly the 32 C3 tracks over the ranks; "
-                         "c5: 30-min tracks")
+                         "c4: the c2 tracks in vpbd_acoustic mode with the Silero network as the chunked VAD; c5: 30-min tracks")
     ap.add_argument("--track-seconds", type=float, default=None, help="default 240 (c2 / c3) or 1800 (c5)")
     ap.add_argument("--items-per-forward", type=int, default=32)
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=240.0,
+                    help="length of the C2 track's prefix the CPU oracle is timed on (default: the whole 240 s track, about 170 s of CPU "
+                         "on 16 threads); 0 disables the CPU baseline leg")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="tracks in flight per GPU (audio_cut_amd.batch.TrackPipeline): 1 = strictly one after the other")
     ap.add_argument("--write-golden", default=None, metavar="PATH",
@@ -328,12 +330,24 @@ def main() -> None:
     assert len(mine) == steps
     make = (lambda sd: signals.c5_long_form(track_s, seed=sd)) if args.config == "c5" else (lambda sd: signals.c2_song(track_s, seed=sd))
     depth = max(1, min(int(args.pipeline_depth), steps))
-    splitters = [SeamlessSplitter(sr, separator=EnhancedVocalSeparator(sr, backend=backend)) for _ in range(depth)]
+    mode = "vpbd_acoustic" if args.config == "c4" else "v2.2_mdd"
+    c4_fixture = ROOT / "tests" / "golden" / "c4_full_oracle.npz"
+    vad_fn = None
+    if args.config == "c4":
+        # BASELINE configs[3]: SileroChunkVAD focus windows.  The real Silero weights cannot be fetched offline: seeded synthetic
+        # weights of the v5 architecture (tests/silero_synth.py), output layer calibrated once with the CPU oracle - the two
+        # calibration numbers travel in the committed fixture, so nothing under oracle/ is imported here
+        sys.path.insert(0, str(ROOT / "tests"))
+        from silero_synth import synth_silero_weights
+        from audio_cut_amd.detectors.silero_vad import SileroHipVad
+        fx = np.load(c4_fixture)
+        vad_fn = SileroHipVad(sr, synth_silero_weights(int(fx["silero_seed"]), str(fx["silero_calib"]), affine=fx["silero_affine"]), hip)
+    splitters = [SeamlessSplitter(sr, separator=EnhancedVocalSeparator(sr, backend=backend, vad_inference_fn=vad_fn)) for _ in range(depth)]
     pipeline = batch.TrackPipeline(splitters, device)
     gate = pipeline.separation_gate if depth > 1 else None
 
     def job_for(mix, mix_dev):
-        return lambda sp: sp.split_track(mix, audio_dev=mix_dev, separation_gate=gate)
+        return lambda sp: sp.split_track(mix, mode=mode, audio_dev=mix_dev, separation_gate=gate)
 
     # every timed track is generated and made resident in HBM before the clock starts (BASELINE contract); warm-up tracks are
     # tracks of their own (seeds 50, 51, ...) so nothing of a timed track has been seen before
@@ -392,13 +406,30 @@ def main() -> None:
         achieved = flops / (unet_ms / 1e3) / 1e12 if unet_ms > 0 else 0.0
         # "per-track boundaries identical to the single-GPU run" (SURVEY.md 8d C3): every track against the committed N = 1 result
         golden = {}
-        if C3_GOLDEN.exists() and args.config != "c5" and track_s == 240.0:
+        if C3_GOLDEN.exists() and args.config in ("c2", "c3") and track_s == 240.0:
             golden = json.loads(C3_GOLDEN.read_text()).get("tracks", {})
         checked = [(d, golden[str(d["seed"])]) for d in all_summaries if str(d["seed"]) in golden]
         bad = [d["seed"] for d, g in checked if d["boundaries_sha1"] != g["boundaries_sha1"] or d["cuts_sha1"] != g["cuts_sha1"]]
         parity = {"reference": "tests/golden/c3_n1_sha1.json (bench.py --config c3 --write-golden on one GPU)" if golden else None,
                   "tracks_checked": len(checked), "tracks_identical": len(checked) - len(bad), "mismatched_seeds": bad,
                   "unchecked_seeds": [d["seed"] for d in all_summaries if str(d["seed"]) not in golden]}
+        # the seed-2 track is BASELINE configs[1] / [3] itself: its guard boundaries and manifest cuts against the CPU oracle's
+        # committed result (tests/golden/c2_full_oracle.npz, c4_full_oracle.npz: data, written by tests/golden/make_*.py)
+        oracle_fx = {"c2": ROOT / "tests" / "golden" / "c2_full_oracle.npz", "c4": c4_fixture}.get(args.config)
+        vs_oracle = None
+        if oracle_fx is not None and oracle_fx.exists() and track_s == 240.0:
+            for st_res, d in zip(step_results, summaries):
+                if d["seed"] == 2:
+                    fx = np.load(oracle_fx)
+                    vs_oracle = {"fixture": str(oracle_fx.relative_to(ROOT)), "seed": 2,
+                                 "boundaries_exact": [int(v) for v in st_res["sample_boundaries"]] == fx["sample_boundaries"].tolist(),
+                                 "manifest_cuts_exact": [int(v) for v in st_res.get("cuts_samples", [])] == fx["cuts"].tolist(),
+                                 "n_boundaries": int(len(fx["sample_boundaries"]))}
+                    if args.config == "c4":
+                        vs_oracle["vpbd_selected_exact"] = list(st_res.get("vpbd_selected_times", [])) == fx["vpbd_selected"][:, 0].tolist()
+                        vs_oracle["vad_segments"] = len(st_res.get("vad_segments") or [])
+        parity["vs_cpu_oracle_fixture"] = vs_oracle
+        parity_ok = (not bad) and (vs_oracle is None or all(v for k, v in vs_oracle.items() if k.endswith("_exact")))
         if args.write_golden and args.config == "c3" and world == 1:
             Path(args.write_golden).write_text(json.dumps({"what": "per-track SHA-1 of the guard boundaries and of the manifest cuts of the 32 C3 tracks "
                                                      "(c2_song 240 s, seeds 100-131, synth weights seed 0), one MI355X, bench.py --config c3",
@@ -410,11 +441,17 @@ def main() -> None:
                   "quiet-guard + boundary policy; one track per step, every step a different seed, resident in HBM"
                   + ("" if world == 1 else f"; N > 1: the C3 seeds 100..{C3_SEED0 + world * steps - 1} dealt by assign_tracks"),
             "c3": "BASELINE configs[2]: the 32 x 4-min C3 tracks (seeds 100-131) dealt over the ranks by assign_tracks, same path as configs[1]",
+            "c4": "BASELINE configs[3]: the configs[1] tracks in vpbd_acoustic mode - chunked MDX23 separation + TrackFeatureCache + SileroChunkVAD "
+                  "(the Silero v5 network as HIP kernels, seeded synthetic weights) focus windows + PureVocalPauseDetector + VPBD candidate pool / "
+                  "scoring / global planner + quiet-guard + boundary policy; one track per step, resident in HBM",
             "c5": "BASELINE configs[4] after the loader: 30-min 44.1 kHz long-form track (C2 generator looped with per-section seeds), "
                   "240 chunks / 480 U-Net items per track, same path as configs[1]",
         }
         out = {
             "metric": METRIC, "value": round(total_audio / elapsed, 3), "unit": "audio-s/s", "n_gpus": world,
+            "value_is": "WHOLE-JOB aggregate over n_gpus (all ranks' audio seconds / max-over-ranks wall time), as the bench contract "
+                        "prescribes; divide by n_gpus for the per-GPU figure the metric's name refers to",
+            "value_per_gpu": round(total_audio / elapsed / world, 3), "parity_ok": bool(parity_ok),
             "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
@@ -443,6 +480,8 @@ def main() -> None:
             "n_boundaries": all_summaries[0]["n_boundaries"], "boundaries_sha1": all_summaries[0]["boundaries_sha1"],
             "n_manifest_cuts": len(step_results[0].get("cuts_samples", [])), "segment_layout_applied": bool(step_results[0].get("segment_layout_applied", False)),
             "tracks_completed": len(all_summaries), "parity_vs_single_gpu": parity,
+            "track_hashes": {str(d["seed"]): {"boundaries_sha1": d["boundaries_sha1"], "cuts_sha1": d["cuts_sha1"], "n_boundaries": d["n_boundaries"]}
+                             for d in all_summaries},
         }
         if world == 1:
             # single-stream latency next to the pipelined throughput: one more track, strictly alone on the GPU (outside the timed region)
@@ -463,6 +502,11 @@ def main() -> None:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    # a throughput figure on top of boundaries that differ from the committed single-GPU / CPU-oracle results is not a result:
+    # fail the run.  That includes the one-GPU rehearsal of the N > 1 control flow (AC_BENCH_REHEARSAL=1, ranks sharing one device):
+    # the corruption that mode showed in round 2 was a kernel-level defect, found and removed in round 3.
+    if rank == 0 and not parity_ok:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

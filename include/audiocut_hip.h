@@ -219,7 +219,9 @@ int ac_tdf_small_fused(ac_ctx* ctx, const float* x, const void* w1_packed, const
  *   up:   out[b][co][2y+dy][2x+dx] = relu(bias[co] + w_unscale * sum x[b][ci][y][x] w[ci][co][dy][dx]) * skip[...]  (skip may be NULL)
  * x [B][C_in][H][W] float32 NCHW; w_packed = conv_pack.pack_linear(W, bn=96) of W[co][(ci,dy,dx)] (down) or
  * W[(co,dy,dx)][ci] (up), zero padded to N % 96 == 0, K % 32 == 0.  Pixels per image on the GEMM's M axis
- * ((H/2)*(W/2) down, H*W up) % 128 == 0; W % 4 == 0; down: H even, C_in % 8 == 0; up: 4*C_out % 96 == 0. */
+ * ((H/2)*(W/2) down, H*W up) % 128 == 0; W % 4 == 0; down: H even, C_in % 8 == 0; up: 4*C_out % 96 == 0.
+ * With in_amax / out_amax: down needs (W/2) % 4 == 0, up needs W >= 64 and W % 4 == 0 (a staged quad of pixels is scaled with
+ * the maximum of ONE input row, so it must not straddle two rows). */
 int ac_down2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
                     int H, int W, float w_unscale, const float* in_amax, float* out_amax, void* stream);
 int ac_up2x_f16x3(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, const float* skip, float* out, int B,

@@ -74,19 +74,24 @@ def resample_to_16k(audio: np.ndarray, sr: int) -> np.ndarray:
     return scipy.signal.resample_poly(np.asarray(audio, dtype=np.float32), SR16 // g, int(sr) // g).astype(np.float32)
 
 
-def detect_speech_timestamps(audio: np.ndarray, sr: int, weights: Weights) -> List[Dict[str, int]]:
-    """vocal_pause_detector.py:175-296 (static parameters: `current_adaptive_params` is always None on the live path)."""
+def detect_speech_timestamps(audio: np.ndarray, sr: int, weights: Weights, adaptive=None) -> List[Dict[str, int]]:
+    """vocal_pause_detector.py:175-296.  `adaptive` = (vad_threshold, min_pause_duration [s], speech_pad_ms): the
+    `current_adaptive_params` branch (`:198-206`); None = the static parameters of the live path."""
     a16 = resample_to_16k(audio, sr)
     n16 = a16.shape[0]
     bucket = int(get_config("advanced_vad.silero_length_bucket", 4096))
     if bucket > 0 and (-n16) % bucket:
         a16 = np.pad(a16, (0, (-n16) % bucket), mode="constant")
     probs = silero_probs(weights, a16)
-    stamps = speech_timestamps(probs, len(a16), WINDOW, SR16,
-                               threshold=float(get_config("advanced_vad.silero_prob_threshold_down", 0.35)),
+    if adaptive is not None:
+        thr, min_sil, pad = float(adaptive[0]), float(int(float(adaptive[1]) * 1000)), float(int(adaptive[2]))
+    else:
+        thr = float(get_config("advanced_vad.silero_prob_threshold_down", 0.35))
+        min_sil = float(get_config("advanced_vad.silero_min_silence_ms", 700))
+        pad = float(get_config("advanced_vad.silero_speech_pad_ms", 150))
+    stamps = speech_timestamps(probs, len(a16), WINDOW, SR16, threshold=thr,
                                min_speech_ms=float(get_config("advanced_vad.silero_min_speech_ms", 250)),
-                               min_silence_ms=float(get_config("advanced_vad.silero_min_silence_ms", 700)),
-                               pad_ms=float(get_config("advanced_vad.silero_speech_pad_ms", 150)))
+                               min_silence_ms=min_sil, pad_ms=pad)
     out: List[Dict[str, int]] = []
     for ts in stamps:
         a = int(max(0, min(ts.get("start", 0), n16))); b = int(max(0, min(ts.get("end", 0), n16)))

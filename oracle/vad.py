@@ -46,7 +46,7 @@ def speech_timestamps(probs: np.ndarray, n_samples: int, win: int, sr: int, thre
     min_speech = sr * min_speech_ms / 1000.0
     pad = sr * pad_ms / 1000.0
     min_silence = sr * min_silence_ms / 1000.0
-    neg = threshold - 0.15
+    neg = max(threshold - 0.15, 0.01)          # silero_vad.get_speech_timestamps: neg_threshold = max(threshold - 0.15, 0.01)
     triggered = False
     speeches: List[Dict[str, int]] = []
     cur: Dict[str, int] = {}

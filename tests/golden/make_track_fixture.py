@@ -63,9 +63,11 @@ def main() -> None:
     mix = np.mean(mix, axis=0).astype(np.float32) if mix.ndim == 2 else mix
     w = synth_weights(TfcTdfSpec(), seed=a.weights)
     kw = {}
+    affine = (np.nan, np.nan)
     if a.silero is not None:
-        from silero_synth import synth_silero_weights
-        kw["vad_fn"] = OS.silero_vad_fn(sr, synth_silero_weights(a.silero, calib=a.silero_calib))
+        from silero_synth import calibration_affine, synth_silero_weights
+        affine = calibration_affine(a.silero, a.silero_calib)       # stored: the GPU test and bench.py rebuild the weights from it without the oracle
+        kw["vad_fn"] = OS.silero_vad_fn(sr, synth_silero_weights(a.silero, calib=a.silero_calib, affine=affine))
     t0 = time.time()
     ref = OE.run_track(mix, sr, w, **kw)
     print(f"oracle: {time.time() - t0:.1f} s, {len(ref.sample_boundaries)} boundaries, {len(ref.pauses)} pauses, "
@@ -115,7 +117,7 @@ def main() -> None:
     np.savez_compressed(
         ROOT / "tests" / "golden" / f"{a.name}.npz", seconds=np.float64(a.seconds), seed=np.int64(a.seed), weight_seed=np.int64(a.weights),
         generator=np.asarray(a.generator), silero_seed=np.int64(-1 if a.silero is None else a.silero), silero_calib=np.asarray(a.silero_calib),
-        mode=np.asarray(a.mode), numpy_version=np.asarray(np.__version__),
+        silero_affine=np.asarray(affine, dtype=np.float64), mode=np.asarray(a.mode), numpy_version=np.asarray(np.__version__),
         sample_boundaries=np.asarray(bounds, dtype=np.int64), cuts=np.asarray(cuts, dtype=np.int64),
         flags=np.asarray(policy.flags if policy is not None else [], dtype=np.int8),
         pieces=np.asarray(policy.pieces if policy is not None else [], dtype=np.int64).reshape(-1, 2),

@@ -57,9 +57,11 @@ def calibration_affine(seed: int = 0, calib: str = "voice"):
     logit = np.log(np.clip(p, 1e-7, 1 - 1e-7) / np.clip(1 - p, 1e-7, 1))
     nw = len(p)
     energy = np.log10(np.mean(np.square(np.pad(clip, (0, nw * 512 - len(clip))).reshape(nw, 512)), axis=1) + 1e-12)
-    lo, hi = np.quantile(logit, 0.2), np.quantile(logit, 0.8)
+    # "c2_stem": the stem is quiet and even, its phrases are the loudest third of the windows: centre the logistic higher and
+    # make it steeper (with seed 3: 11 speech segments in the first minute; 0.2 / 0.8 gives one segment spanning the track)
+    lo, hi = (np.quantile(logit, 0.6), np.quantile(logit, 0.95)) if calib == "c2_stem" else (np.quantile(logit, 0.2), np.quantile(logit, 0.8))
     sign = 1.0 if np.corrcoef(logit, energy)[0, 1] >= 0 else -1.0
-    a = sign * 5.0 / max(hi - lo, 1e-3)
+    a = sign * (8.0 if calib == "c2_stem" else 5.0) / max(hi - lo, 1e-3)
     b = -a * 0.5 * (hi + lo)
     return float(a), float(b)
 

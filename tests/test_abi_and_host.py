@@ -227,3 +227,30 @@ def test_runtime_override_of_a_section_is_seen_by_child_lookups():
         assert C.get_config("quality_control")["enforce_quiet_cut"] == {"enable": False}
     finally:
         C.restore(saved)
+
+
+def test_library_has_no_packed_float32_instructions(tmp_path):
+    """The device code of libaudiocut_hip.so must not contain packed-float32 VALU instructions (csrc/Makefile NOPK).
+    Measured on MI355X (profiles/r03_gpu_sharing_rootcause.log): `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` - what hipcc's SLP
+    vectoriser makes of float2 complex arithmetic - returns wrong values for a quarter-wave at a time while a workgroup of the MFMA
+    conv kernels shares the compute unit (another stream or another process alike); that was the "two processes on one GPU"
+    corruption of round 2.  Guards the build flag: a kernel file compiled without it would bring the instructions back."""
+    import shutil
+    import subprocess
+    from audio_cut_amd import _native
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("no llvm-objdump in this image")
+    lib = tmp_path / "lib.so"
+    shutil.copy(_native.library_path(), lib)
+    subprocess.run([str(objdump), "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    parts = sorted(tmp_path.glob("lib.so.*gfx950*"))
+    assert parts, "no gfx950 code object found in the library"
+    n_inst = 0
+    for part in parts:
+        asm = subprocess.run([str(objdump), "-d", str(part)], check=True, capture_output=True, text=True).stdout
+        n_inst += asm.count("v_mfma_f32_16x16x32_f16")
+        bad = [ln.strip() for ln in asm.splitlines() if "v_pk_" in ln and "_f32" in ln.split("v_pk_", 1)[1].split()[0]]
+        bad += [ln.strip() for ln in asm.splitlines() if "v_pk_mov_b32" in ln]
+        assert not bad, f"{len(bad)} packed-float32 instructions in {part.name}, e.g. {bad[:3]}"
+    assert n_inst > 1000          # the disassembly really is the kernels (the conv / GEMM MFMA streams are in there)

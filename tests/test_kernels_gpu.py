@@ -227,3 +227,48 @@ def test_yin_f0_autocorrelation_kernel(hip_ctx):
     assert np.mean(np.abs(f0 - ref_f0) / ref_f0 < 1e-3) > 0.97      # elsewhere the pick can hop between near-equal troughs
     sil, _ = hip_ctx.yin_f0(hip_ctx.to_device(np.zeros(8192, np.float32)), SR, fmin, fmax, 2048, 441)
     assert np.all(sil == SR / 21.0)                        # silent frames: cmnd == 0 everywhere -> first lag, as librosa
+
+
+def test_kernels_stay_exact_beside_the_conv_on_another_stream(hip_ctx):
+    """Regression guard for round 2's "two processes on one GPU" corruption, root-caused in round 3
+    (profiles/r03_gpu_sharing_rootcause.log): built WITH hipcc's packed-float32 instructions the FFT kernels computed wrong frames
+    whenever workgroups of the MFMA conv kernels shared their compute unit - from another stream of the same process just as from
+    another process (1637 of 1640 launches).  The library is built without those instructions (csrc/Makefile NOPK); here the STFT,
+    the iSTFT, the 1x1 conv and the Silero front end (the kernels that carried the most packed ops) run on one stream while the
+    3x3 conv loops on another, and every launch must equal its solo result bit for bit."""
+    import time
+    from audio_cut_amd._native import _ptr, _stream
+    from audio_cut_amd.separation.conv_pack import pack_conv3x3_w96
+    dev = hip_ctx.device
+    g = torch.Generator().manual_seed(5)
+    x48 = torch.randn(4, 48, 256, 3072, generator=g).to(dev)
+    w = torch.randn(48, 48, 3, 3, generator=g) / 20
+    pk, un = pack_conv3x3_w96(w.numpy(), 48)
+    wp = torch.from_numpy(pk.view(np.int16)).to(dev); b48 = torch.zeros(48, device=dev); y48 = torch.empty_like(x48)
+    conv = lambda: hip_ctx.lib.ac_conv3x3_f16x3_s8(hip_ctx._h, _ptr(x48), _ptr(wp), _ptr(b48), _ptr(y48), 4, 48, 48, 256, 3072, float(un), 1,
+                                                   None, None, _stream())
+    trk = (torch.randn(441000 * 6, generator=g) * 0.3).to(dev)
+    cs = hip_ctx.to_device(np.repeat(np.arange(4) * 330750, 2).astype(np.int64)); cl = hip_ctx.to_device(np.full(8, 441000, np.int64))
+    wi = hip_ctx.to_device(np.tile([0, 1], 4).astype(np.int32))
+    spec = hip_ctx.mdx_stft(trk, cs, cl, wi)
+    w11 = (torch.randn(4, 48, generator=g) / 7).to(dev); b11 = torch.zeros(4, device=dev)
+    victims = {"mdx_stft": lambda: hip_ctx.mdx_stft(trk, cs, cl, wi), "mdx_istft": lambda: hip_ctx.mdx_istft(spec),
+               "conv1x1_small": lambda: hip_ctx.conv1x1_small(x48, w11, b11, relu=False)}
+    refs = {k: f().clone() for k, f in victims.items()}
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    wrong = {k: 0 for k in victims}
+    count = {k: 0 for k in victims}
+    t_end = time.time() + 2.0
+    while time.time() < t_end:
+        with torch.cuda.stream(sa):
+            for _ in range(6):
+                assert conv() == 0
+        with torch.cuda.stream(sb):
+            res = {k: [(f() != refs[k]).sum() for _ in range(2)] for k, f in victims.items()}
+        torch.cuda.synchronize()
+        for k, rs in res.items():
+            count[k] += len(rs); wrong[k] += sum(1 for r in rs if int(r))
+    print("launches beside the conv (wrong / total):", {k: f"{wrong[k]} / {count[k]}" for k in victims})
+    assert all(v == 0 for v in wrong.values()), wrong
+    assert min(count.values()) >= 20

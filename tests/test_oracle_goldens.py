@@ -200,3 +200,72 @@ def test_pyin_building_blocks_known_answers():
         z[i] = 1.5 * z[i - 1] - 0.8 * z[i - 2] + e[i]
     a = L.lpc(z, 2)
     assert np.allclose(a, [1.0, -1.5, 0.8], atol=0.05)
+
+
+def test_guard_plateau_predicate_and_soak_fixture(golden_dir):
+    """tests/guard_plateau.py (the equivalence class of a guard boundary decided inside digital silence): the predicate accepts a
+    moved boundary only on the epsilon plateau and only where the ORACLE's own dB series are bit-equal; the committed soak
+    fixture (seed 301 / weights 61 / Silero 1) is consistent with it and every interior boundary of that track is such a decision."""
+    import sys
+    sys.path.insert(0, str(golden_dir.parent))
+    from guard_plateau import HALF, boundary_context, classify_boundaries, map_cuts, plateau_db
+    g = np.load(golden_dir / "c1_60s_seed301_w61_silero1_oracle.npz")
+    plat = plateau_db()
+    assert float(g["plateau_db"]) == float(plat) and abs(float(plat) + 119.999991) < 1e-5
+    b = g["sample_boundaries"]
+    assert int(g["guard_half_window"]) == HALF and g["db_vocal"].shape == (len(b), 2 * HALF + 1)
+    on = g["on_plateau"]
+    assert not on[0] and not on[-1] and int(on.sum()) == len(b) - 2
+    assert np.all(g["db_vocal"][on, HALF] == plat) and np.all(g["db_mix"][on, HALF] == plat)
+    ctx = {k: g[k] for k in ("on_plateau", "db_vocal", "db_mix", "stem_window", "guard_half_window")}
+    n = int(round(float(g["seconds"]) * 44100))
+    stem = np.zeros(n, np.float32)
+    for k, bb in enumerate(b):                       # a stem that agrees with the oracle's around every boundary
+        lo, hi = max(0, bb - HALF), min(n, bb + HALF + 1)
+        stem[lo:hi] = g["stem_window"][k][lo - (bb - HALF): hi - (bb - HALF)]
+    want = b.tolist()
+    exact, equiv, fails = classify_boundaries(want, want, ctx, stem, 1e-9)
+    assert len(exact) == len(want) and not equiv and not fails
+    # the round-2 GPU result: boundary 2407367 -> 2407370, inside the plateau
+    k = want.index(2407367)
+    assert g["db_vocal"][k][HALF + 3] == plat and g["db_mix"][k][HALF + 3] == plat
+    got = list(want); got[k] = 2407370
+    exact, equiv, fails = classify_boundaries(got, want, ctx, stem, 1e-9)
+    assert equiv == [(2407370, 2407367)] and not fails and len(exact) == len(want) - 1
+    assert map_cuts([0, 2407370, n], equiv) == [0, 2407367, n]
+    # moved to where the oracle's series is NOT the plateau value: rejected; so is any move of a boundary off the plateau
+    off = int(np.flatnonzero(g["db_vocal"][k] != plat)[0]) - HALF
+    got[k] = 2407367 + off
+    assert classify_boundaries(got, want, ctx, stem, 1e-9)[2]
+    ctx2 = dict(ctx); ctx2["on_plateau"] = np.zeros_like(on)
+    got[k] = 2407370
+    assert classify_boundaries(got, want, ctx2, stem, 1e-9)[2]
+    # and a stem that differs around the boundary is rejected even on the plateau
+    bad_stem = stem.copy(); bad_stem[2407367 - 100] += 1e-3
+    assert classify_boundaries(got, want, ctx, bad_stem, 1e-5)[2]
+    # boundary_context on synthetic data: exact zeros -> plateau, a tone -> not
+    x = np.zeros(44100, np.float32); x[:20000] = 0.3 * np.sin(np.arange(20000) * 0.05).astype(np.float32)
+    c = boundary_context(x, x, [10000, 35000], 44100, half=64)
+    assert c["on_plateau"].tolist() == [False, True]
+
+
+def test_c4_fixture_is_self_consistent_and_its_vad_calibration_is_the_oracles(golden_dir):
+    """tests/golden/c4_full_oracle.npz (BASELINE configs[3] at full size): the stored Silero output-layer calibration is what
+    `silero_synth.calibration_affine` derives with the CPU oracle (the GPU test and bench.py rebuild the weights from the two stored
+    numbers without importing the oracle), the VAD really segments the track, and the VPBD counts add up."""
+    import sys
+    sys.path.insert(0, str(golden_dir.parent))
+    from silero_synth import calibration_affine, synth_silero_weights
+    g = np.load(golden_dir / "c4_full_oracle.npz")
+    assert str(g["mode"]) == "vpbd_acoustic" and float(g["seconds"]) == 240.0 and int(g["seed"]) == 2 and str(g["generator"]) == "c2_song"
+    a, b = calibration_affine(int(g["silero_seed"]), str(g["silero_calib"]))
+    assert (a, b) == tuple(g["silero_affine"].tolist())
+    w1 = synth_silero_weights(int(g["silero_seed"]), str(g["silero_calib"]), affine=g["silero_affine"])
+    assert w1["decoder.decoder.2.bias"].shape == (1,) and np.isfinite(w1["decoder.decoder.2.weight"]).all()
+    vad = g["vad_segments"]
+    assert len(vad) >= 8 and np.all(vad[:, 1] > vad[:, 0]) and np.all(vad[1:, 0] >= vad[:-1, 1])
+    acoustic, beat, merged, total, selected, suppressed = g["vpbd_counts"].tolist()
+    assert selected == len(g["vpbd_selected"]) >= 10 and suppressed == len(g["vpbd_suppressed"]) and selected + suppressed == total
+    sb = g["sample_boundaries"]
+    assert sb[0] == 0 and sb[-1] == 240 * 44100 and np.all(np.diff(sb) > 0) and len(sb) >= 10
+    assert g["cuts"][0] == 0 and g["cuts"][-1] == 240 * 44100 and not g["on_plateau"].any()

@@ -52,6 +52,19 @@ def test_silero_weight_files_and_oracle_contract(tmp_path):
         C.restore(saved)
 
 
+def test_negative_threshold_has_silero_vads_floor():
+    """silero_vad.get_speech_timestamps clamps neg_threshold to max(threshold - 0.15, 0.01): with a configured threshold <= 0.15 a
+    triggered segment must still be able to close (product hysteresis == oracle hysteresis)."""
+    from audio_cut_amd.detectors.silero_chunk_vad import speech_timestamps as product
+    from oracle.vad import speech_timestamps as oracle
+    probs = np.concatenate([np.full(40, 0.9), np.full(60, 0.005), np.full(30, 0.9), np.full(50, 0.02)]).astype(np.float32)
+    for thr in (0.1, 0.15, 0.35):
+        got = product(probs, 512 * len(probs), 512, 16000, thr, 250.0, 700.0, 150.0)
+        assert got == oracle(probs, 512 * len(probs), 512, 16000, thr, 250.0, 700.0, 150.0)
+    low = product(probs, 512 * len(probs), 512, 16000, 0.1, 250.0, 700.0, 0.0)
+    assert len(low) == 2 and low[0]["end"] == 40 * 512        # closed at the first window under 0.01, not never
+
+
 @pytest.mark.gpu
 def test_silero_network_and_timestamps_against_oracle(hip_ctx):
     """Window probabilities within 1e-5 of the torch-CPU oracle (float32 both sides; the 16 kHz input differs by the float32
@@ -80,6 +93,14 @@ def test_silero_network_and_timestamps_against_oracle(hip_ctx):
         assert single == want
         assert np.array_equal(vad.precompute(hip_ctx.to_device(c), [0], [len(c)])[0].probs, p.probs)
     assert n_speech >= 5                                  # the hysteresis really produced segments
+    # the reference's adaptive branch (vocal_pause_detector.py:198-206): threshold, minimum pause and padding per call
+    vad.set_adaptive_params(vad_threshold=0.5, min_pause_duration=0.3, speech_pad_ms=60)
+    for c, p in zip(chunks[:3], pre[:3]):
+        want = OS.detect_speech_timestamps(c, SR, w, adaptive=(0.5, 0.3, 60))
+        assert vad(p) == want
+        assert want != OS.detect_speech_timestamps(c, SR, w) or not want
+    vad.set_adaptive_params()
+    assert vad(pre[0]) == OS.detect_speech_timestamps(chunks[0], SR, w)
 
 
 @pytest.mark.gpu
