@@ -268,6 +268,8 @@ def main() -> None:
                          "on 16 threads); 0 disables the CPU baseline leg")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="tracks in flight per GPU (audio_cut_amd.batch.TrackPipeline): 1 = strictly one after the other")
+    ap.add_argument("--no-separation-gate", action="store_true",
+                    help="experiment: let the U-Nets of the tracks in flight run concurrently (default: one separation on the GPU at a time)")
     ap.add_argument("--write-golden", default=None, metavar="PATH",
                     help="(c3, N = 1) write the per-track SHA-1 table of this run to PATH (committed as tests/golden/c3_n1_sha1.json)")
     args = ap.parse_args()
@@ -344,7 +346,7 @@ def main() -> None:
         vad_fn = SileroHipVad(sr, synth_silero_weights(int(fx["silero_seed"]), str(fx["silero_calib"]), affine=fx["silero_affine"]), hip)
     splitters = [SeamlessSplitter(sr, separator=EnhancedVocalSeparator(sr, backend=backend, vad_inference_fn=vad_fn)) for _ in range(depth)]
     pipeline = batch.TrackPipeline(splitters, device)
-    gate = pipeline.separation_gate if depth > 1 else None
+    gate = pipeline.separation_gate if (depth > 1 and not args.no_separation_gate) else None
 
     def job_for(mix, mix_dev):
         return lambda sp: sp.split_track(mix, mode=mode, audio_dev=mix_dev, separation_gate=gate)
