@@ -47,7 +47,7 @@ def test_c3_single_gpu_table_agrees_with_the_cpu_oracle(golden_dir=None):
     import numpy as np
     gd = Path(__file__).resolve().parent / "golden"
     table = json.loads((gd / "c3_n1_sha1.json").read_text())["tracks"]
-    assert sorted(int(k) for k in table) == list(range(100, 132))
+    assert sorted(int(k) for k in table) == [2] + list(range(100, 132))      # the C2 bench track (seed 2) + the 32 C3 tracks
     for seed in (100, 131):
         g = np.load(gd / f"c3_seed{seed}_oracle.npz")
         assert int(g["seed"]) == seed and float(g["seconds"]) == 240.0
