@@ -37,7 +37,7 @@ def load() -> C.CDLL:
                           f"(there is no CPU fallback for the HIP path)")
     lib = C.CDLL(str(path))
     _declare(lib)
-    if lib.ac_abi_version() != 3:
+    if lib.ac_abi_version() != 4:
         raise NativeError("libaudiocut_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -73,6 +73,7 @@ SIGNATURES = {
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_w96": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_s8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
+    "ac_conv3x3_f16x3_mix": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_first": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, C.c_float, C.c_float,
                                          _P, _P]),
     "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P, _P, _P]),
@@ -225,20 +226,51 @@ class Context:
         return float(sr) / period.cpu().numpy(), cmnd
 
     # -- loader / exporter ---------------------------------------------------
+    # libsoxr's HQ recipe as published (soxr.c `soxr_quality_spec(SOXR_HQ)`, rate.h): 20-bit precision, linear phase, stop band from
+    # the Nyquist frequency of the lower rate, pass band to 1 - 0.05 / TO_3dB(20 bits * 6.0206 dB) = 0.91363 of it, low-pass designed
+    # for (20 + 1) * 6.0206 = 126.43 dB.  The reference resamples with it twice (librosa's default res_type "soxr_hq":
+    # audio_processor.py:44-48 on load, vocal_pause_detector.py:189 in front of Silero).
+    SOXR_HQ_PASSBAND_END = 1.0 - 0.05 / ((1.6e-6 * 120.41199826559248 - 7.5e-4) * 120.41199826559248 + 0.646)
+    SOXR_HQ_ATT_DB = 126.43259817887210
+
     @staticmethod
     def _resample_filter(up: int, down: int):
-        """scipy.signal.resample_poly's default design: Kaiser(5.0) windowed sinc of half length 10 * max(up, down), scaled by
-        `up`, front-padded so that the output is aligned; returns (h float32, n_pre_remove)."""
+        """Anti-alias / anti-image low-pass of a rational resampler to libsoxr's HQ specification (pass band flat to 0.9136 of the
+        lower Nyquist frequency, stop band from that Nyquist on, 126 dB): one Kaiser-windowed sinc at the common rate, sized by
+        `scipy.signal.kaiserord`, in scipy.signal.resample_poly's framing (scaled by `up`, front-padded so that output sample 0 is
+        aligned with input sample 0).  Returns (h float32, n_pre_remove).  libsoxr's own coefficients cannot be reproduced offline
+        (DESIGN.md 6 row 2): this matches its published response, not its bits."""
         import scipy.signal
-        half_len = 10 * max(up, down)
-        h = scipy.signal.firwin(2 * half_len + 1, 1.0 / max(up, down), window=("kaiser", 5.0)).astype(np.float32)
-        h *= up
+        rate = max(up, down)
+        f_pass, f_stop = Context.SOXR_HQ_PASSBAND_END / rate, 1.0 / rate            # in units of the common rate's Nyquist
+        n_taps, beta = scipy.signal.kaiserord(Context.SOXR_HQ_ATT_DB, f_stop - f_pass)
+        n_taps += 1 - (n_taps & 1)                                                  # odd length: zero phase, centred on a tap
+        half_len = (n_taps - 1) // 2
+        h = scipy.signal.firwin(n_taps, 0.5 * (f_pass + f_stop), window=("kaiser", beta), scale=True)    # float64, unit DC gain
+        h = (h * up).astype(np.float32)
         n_pre_pad = down - half_len % down
         n_pre_remove = (half_len + n_pre_pad) // down
         return np.concatenate((np.zeros(n_pre_pad, dtype=np.float32), h)), n_pre_remove
 
+    @staticmethod
+    def _polyphase_rows(h_full: np.ndarray, up: int) -> np.ndarray:
+        """hp[p][t] = h_full[p + t * up], rows zero-padded: the layout ac_resample_poly takes (include/audiocut_hip.h)."""
+        tpp = -(-h_full.size // up)
+        hp = np.zeros(tpp * up, dtype=np.float32)
+        hp[:h_full.size] = h_full
+        return np.ascontiguousarray(hp.reshape(tpp, up).T)
+
+    def _resample_filter_dev(self, up: int, down: int):
+        """(polyphase rows on the device, n_pre_remove) of the (up, down) resampler; designed and uploaded once per context."""
+        cache = self.__dict__.setdefault("_rs_filters", {})
+        if (up, down) not in cache:
+            h, n_pre_remove = self._resample_filter(up, down)
+            cache[(up, down)] = (self.to_device(self._polyphase_rows(h, up).reshape(-1)), n_pre_remove)
+        return cache[(up, down)]
+
     def resample_poly(self, x: torch.Tensor, up: int, down: int) -> torch.Tensor:
-        """scipy.signal.resample_poly(x, up, down) on the device (default Kaiser(5.0) design, zero padding)."""
+        """x at fs -> fs * up / down on the device: poly-phase FIR in scipy.signal.resample_poly's framing (zero padding, aligned, ceil(n up / down)
+        outputs) with the soxr-HQ-specification low-pass of `_resample_filter`."""
         import math
         self._chk_f32(x)
         g = math.gcd(int(up), int(down))
@@ -248,10 +280,9 @@ class Context:
         n = x.numel()
         n_out = n * up
         n_out = n_out // down + bool(n_out % down)
-        h, n_pre_remove = self._resample_filter(up, down)
-        hd = self.to_device(h)
+        hd, n_pre_remove = self._resample_filter_dev(up, down)
         out = torch.empty(n_out, dtype=torch.float32, device=self.device)
-        _check(self.lib.ac_resample_poly(self._h, _ptr(x), n, up, down, _ptr(hd), h.size, n_pre_remove, _ptr(out), n_out, _stream()))
+        _check(self.lib.ac_resample_poly(self._h, _ptr(x), n, up, down, _ptr(hd), hd.numel(), n_pre_remove, _ptr(out), n_out, _stream()))
         return out
 
     def resample_poly_segments(self, x: torch.Tensor, offsets: Sequence[int], lengths: Sequence[int], up: int, down: int, bucket: int = 0):
@@ -274,12 +305,11 @@ class Context:
             for o, n, oo in zip(offsets, lengths, out_off[:-1]):
                 out[int(oo): int(oo) + n] = x[int(o): int(o) + n]
             return out, out_off[:-1], out_len
-        h, n_pre_remove = self._resample_filter(up, down)
-        hd = self.to_device(h)
+        hd, n_pre_remove = self._resample_filter_dev(up, down)
         d_io = self.to_device(np.asarray(offsets, dtype=np.int64)); d_il = self.to_device(np.asarray(lengths, dtype=np.int64))
         d_oo = self.to_device(out_off[:-1].copy()); d_ol = self.to_device(np.asarray(out_len, dtype=np.int64))
         _check(self.lib.ac_resample_poly_segments(self._h, _ptr(x), _ptr(d_io), _ptr(d_il), _ptr(d_oo), _ptr(d_ol), len(lengths), up, down,
-                                                  _ptr(hd), h.size, n_pre_remove, _ptr(out), total, _stream()))
+                                                  _ptr(hd), hd.numel(), n_pre_remove, _ptr(out), total, _stream()))
         return out, out_off[:-1], out_len
 
     # -- Silero VAD network (detectors/silero_vad.py packs the weights) ------------------------------------
@@ -592,6 +622,14 @@ class Context:
                          out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The 8-channel-stage conv kernel with 48 output channels per workgroup (`pack_conv3x3_w96(w, cob=48)` weights)."""
         return self._conv3x3(self.lib.ac_conv3x3_f16x3_s8, "conv3x3_f16x3_s8", x, w_packed, bias, c_out, w_unscale, relu, out,
+                             in_amax, out_amax)
+
+    def conv3x3_f16x3_mix(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
+                          relu: bool = True, out: Optional[torch.Tensor] = None, in_amax: Optional[torch.Tensor] = None,
+                          out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """C_out = 96 k + 48: 96-channel workgroup tiles for the first k blocks and one 48-channel tile, one launch
+        (`pack_conv3x3_mixed` weights)."""
+        return self._conv3x3(self.lib.ac_conv3x3_f16x3_mix, "conv3x3_f16x3_mix", x, w_packed, bias, c_out, w_unscale, relu, out,
                              in_amax, out_amax)
 
     def conv3x3_f16x3_first(self, spec: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,

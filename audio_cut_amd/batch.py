@@ -60,8 +60,13 @@ class TrackPipeline:
         import threading
         import torch
         self._device = torch.device(device)
-        self._workers = [(sp, torch.cuda.Stream(device=self._device)) for sp in splitters]
+        self._workers = [(sp, torch.cuda.Stream(device=self._device, priority=-1)) for sp in splitters]
         self.separation_gate = threading.Lock()      # one U-Net on the GPU at a time: pass it to split_track(separation_gate=...)
+        # Optional: ONE stream for every worker's separation (split_track(unet_stream=...)).  The stream orders the U-Nets of
+        # consecutive tracks itself, so the gate is held only while a track's launches are queued and the next U-Net waits in the
+        # queue behind the running one; the workers' own streams (tails, VAD, detection: small kernels with host round trips) have
+        # the higher priority.
+        self.unet_stream = torch.cuda.Stream(device=self._device, priority=0)
 
     @property
     def depth(self) -> int:

@@ -140,8 +140,11 @@ class EnhancedVocalSeparator:
 
     # ------------------------------------------------------------------------------------------
     def separate_for_detection(self, audio: np.ndarray, *, gpu_context: Optional[PipelineContext] = None,
-                               audio_dev: Optional[torch.Tensor] = None, separation_gate=None) -> SeparationResult:
+                               audio_dev: Optional[torch.Tensor] = None, separation_gate=None, unet_stream=None) -> SeparationResult:
         """`audio_dev` (extension): the same mono track already resident in HBM; skips the upload.
+        `unet_stream` (extension, `batch.TrackPipeline.unet_stream`): the one stream all workers queue their separations on; the
+        gate is then held only while this track's launches are being queued, and the next track's U-Net sits in the queue behind
+        this one (no idle GPU between two tracks).
         `separation_gate` (extension, a lock shared by the workers of a `batch.TrackPipeline`): taken right before this
         track's first separation kernel is queued (its index tables are already uploaded) and released once that work
         has left the GPU (the VAD results are back), before the host-bound tail."""
@@ -152,7 +155,7 @@ class EnhancedVocalSeparator:
         ctx = self._ensure_pipeline_context(audio, gpu_context)
         try:
             vocal, inst, cache, vad_segments, markers, confidence, state = self._separate_with_pipeline(
-                audio, backend, ctx, audio_dev, separation_gate)
+                audio, backend, ctx, audio_dev, separation_gate, unet_stream)
         except Exception as exc:
             ctx.mark_failure("separation", str(exc))
             raise
@@ -163,7 +166,7 @@ class EnhancedVocalSeparator:
             feature_cache=cache, vad_segments=vad_segments, gpu_meta=meta, pipeline_used=ctx.enabled, device_state=state)
 
     def _separate_with_pipeline(self, audio: np.ndarray, backend: IVocalSeparatorBackend, gpu_context: PipelineContext,
-                                audio_dev: Optional[torch.Tensor] = None, separation_gate=None):
+                                audio_dev: Optional[torch.Tensor] = None, separation_gate=None, unet_stream=None):
         if not isinstance(backend, MDX23HipBackend):
             raise RuntimeError("only MDX23HipBackend drives the batched device path")
         sr = self.sample_rate
@@ -196,17 +199,18 @@ class EnhancedVocalSeparator:
                 gate_held.pop()
                 separation_gate.release()
         try:
-            return self._separate_gated(audio, backend, gpu_context, mix_dev, plans, timings, h2d_ms, take_gate, drop_gate)
+            return self._separate_gated(audio, backend, gpu_context, mix_dev, plans, timings, h2d_ms, take_gate, drop_gate, unet_stream)
         finally:
             drop_gate()
 
-    def _separate_gated(self, audio, backend, gpu_context, mix_dev, plans, timings, h2d_ms, take_gate, drop_gate):
+    def _separate_gated(self, audio, backend, gpu_context, mix_dev, plans, timings, h2d_ms, take_gate, drop_gate, unet_stream=None):
         sr = self.sample_rate
         hip = backend.hip
         total = len(audio)
         mix_ready = torch.cuda.Event()
         mix_ready.record()
-        sep = backend.separate_track(mix_dev, sr, plans, timings, defer_sync=True, before_launch=take_gate)
+        sep = backend.separate_track(mix_dev, sr, plans, timings, defer_sync=True, before_launch=take_gate, unet_stream=unet_stream,
+                                     after_launch=drop_gate if unet_stream is not None else None)
         sep_done = torch.cuda.Event()
         sep_done.record()
 

@@ -71,7 +71,8 @@ class SeamlessSplitter:
         return self._hip
 
     # ------------------------------------------------------------------------------------------
-    def split_track(self, original_audio: np.ndarray, mode: str = "v2.2_mdd", *, audio_dev=None, separation_gate=None) -> Dict:
+    def split_track(self, original_audio: np.ndarray, mode: str = "v2.2_mdd", *, audio_dev=None, separation_gate=None,
+                    unet_stream=None) -> Dict:
         """Steps 2-9 of SURVEY.md §3.1 on an in-memory mono float32 track at `sample_rate`.
         `separation_gate` (a lock shared by the workers of a `batch.TrackPipeline`): held from this track's first separation
         kernel until its U-Net has left the GPU, released before the host-bound tail so that the next track overlaps it.  (Queueing the
@@ -84,7 +85,7 @@ class SeamlessSplitter:
             raise ValueError("split_track needs a non-empty mono track")
         t0 = time.perf_counter()
         sep: SeparationResult = self.separator.separate_for_detection(original_audio, gpu_context=None, audio_dev=audio_dev,
-                                                                     separation_gate=separation_gate)
+                                                                     separation_gate=separation_gate, unet_stream=unet_stream)
         t_sep = time.perf_counter() - t0
         state = sep.device_state or {}
         vocal_track = sep.vocal_track

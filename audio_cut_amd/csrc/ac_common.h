@@ -179,6 +179,23 @@ __device__ inline void ac_amax_commit_blocks(float m, int blk, float* __restrict
     }
 }
 
+// ---- rational-rate polyphase FIR (ac_resample_poly, ac_resample_poly_segments) ----------------------------------------------------
+// y[m] = sum_q hfull[i - q * up] x[q], i = (m + n_pre_remove) * down, over the n samples of x only (zero extension).  The taps
+// arrive as polyphase ROWS hp[p][t] = hfull[p + t * up] (p < up, t < tpp; rows zero-padded): output m uses row p = i % up against
+// x[i / up - t], so a thread walks one contiguous row and a contiguous run of x (the row-major full filter made every tap of every
+// thread its own cache line: 32x the L1 / L2 traffic at the 200-500 taps per output of the soxr-HQ-specification filters).
+// float64 accumulation in ascending q.
+__device__ inline float ac_polyphase_dot(const float* __restrict__ x, int64_t n, const float* __restrict__ hp, int up, int tpp, int64_t i) {
+    const int64_t j0 = i / up;
+    const float* __restrict__ row = hp + (int64_t)(i - j0 * up) * tpp;
+    int64_t t_lo = j0 - (n - 1);                       // q = j0 - t <= n - 1
+    if (t_lo < 0) t_lo = 0;
+    int64_t t_hi = j0 < tpp - 1 ? j0 : tpp - 1;        // q >= 0
+    double acc = 0.0;
+    for (int64_t t = t_hi; t >= t_lo; --t) acc += (double)row[t] * (double)x[j0 - t];
+    return (float)acc;
+}
+
 // Block-wide sum of doubles for blockDim.x == 256 (4 waves); result valid in every thread.
 __device__ inline double block_sum_f64_256(double v, double* smem4) {
     v = wave_sum_f64(v);

@@ -32,9 +32,25 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define W9_PROBE 0                   // bit mask of ablations for the probe builds of tools/sharing_probe_*.py (never the product):
 #endif                               // 1 weights first in LDS, 2 no LDS-DMA, 4 no MFMA, 8 no activation staging, 0x10 no shared tap-8 step,
                                      // 0x20 no epilogue, 0x40 no K loop, 0x80 no activation loads
+#ifndef W9_PIPE
+#define W9_PIPE 1                    // software-pipelined fragment reads in the K loop (0: the compiler's schedule, kept for A/B runs)
+#endif
+#ifndef W9_S8_OCC
+#define W9_S8_OCC 3                  // workgroups per CU of the 48-channel variant
+#endif
 #ifndef W9_FIRST_OCC
 #define W9_FIRST_OCC 3               // workgroups per CU of the fused first conv
 #endif
+
+// One 1 KB piece global -> LDS (16 B per lane, lane i lands at lds + 16 i), issued from inline assembly ON PURPOSE: with the
+// builtin the compiler knows an LDS-DMA is in flight and then drains lgkmcnt to 0 in front of every use of a ds_read result for as
+// long as it is pending (measured on the ISA: every fragment wait in the K loop was lgkmcnt(0)); hidden from it, its counted
+// lgkmcnt(N) waits are exact again and fragment reads can stay in flight behind the MFMAs.  The wave's own s_waitcnt vmcnt(0)
+// in front of the stage barrier is what orders the data (as before); M0 is not used by anything else in these kernels.
+__device__ __forceinline__ void w9_dma16(const void* g, void* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory");
+}
 
 __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
@@ -51,11 +67,12 @@ __device__ __forceinline__ f32x4 w9_mfma(f16x8 a, f16x8 b, f32x4 c) { return __b
 // them per staged pixel (s_first = [C_in][w1[0..3], b1] in LDS; float32 FMAs in ac_conv1x1_small's order, so the values are
 // bit-identical to running that kernel first) - the C_in-channel tensor never touches HBM and the K loop has no activation loads.
 template <int MT, bool RELU, bool ROWX, bool FIRST>
-__device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8* __restrict__ wpk, const float* __restrict__ bias,
+__device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8* __restrict__ wbase /* this channel block's fragments */, const float* __restrict__ bias,
                                         float* __restrict__ out, int C_in, int C_out, int H, int W, float w_unscale,
                                         float* __restrict__ out_amax, unsigned char* s_raw, const int* s_ex, int ex_min,
-                                        int cob, int b, int y0, int x0, const float* s_first, int C0) {
-    constexpr int W9_MT = MT, W9_COB = 16 * MT;
+                                        int co_base, int b, int y0, int x0, const float* s_first, int C0) {
+    constexpr int W9_MT = MT;
+    constexpr bool PIPE = W9_PIPE && MT == 6 && !ROWX;             // the 48-channel variant has no registers for it under its 168-VGPR cap (measured: spills, 40 % slower)
     constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
     constexpr int EP_M = (MT == 6) ? 3 : 2;                   // row tiles per epilogue pass (the output tile must fit the arena)
 #if W9_PROBE & 1                      // probe build: weight buffers first, so every LDS-DMA lands 1 KiB aligned
@@ -87,6 +104,12 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     }
     const float unscale = w_unscale * (ex_min == AC_EX_NONE ? 1.f : ldexpf(1.f, -ex_min));
 
+    // B fragment of (k-step ks, pixel group q): u16 offset b_tap[ks] + a compile-time constant of q (it becomes the ds_read's offset field)
+    const int b_lane = ((2 * wave) * W9_RS + px + 3) * W9_CB;                  // patch column c is staged column c + 3
+    int b_tap[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { const int tap = 4 * ks + g; b_tap[ks] = b_lane + ((tap / 3) * W9_RS + (tap % 3)) * W9_CB; }
+
     f32x4 acc[W9_MT][4];
 #pragma unroll
     for (int m = 0; m < W9_MT; ++m)
@@ -97,7 +120,6 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     for (int q = 0; q < 4; ++q) { k8h[q] = (f16x8)(_Float16)0; k8l[q] = (f16x8)(_Float16)0; }
 
     // fragments per stage in the packed weights: [cob][cb][3 k-steps][2][6][64]; the third k-step exists for cb & 3 == 3 only
-    const f16x8* wbase = wpk + (size_t)cob * n_cb * 3 * W9_KFR;
 
     int a_src = -1;
     const int a_off = ((a_row * W9_RS + 4 * a_qd) * W9_CB + a_c4 * 4);         // u16 elements
@@ -133,7 +155,10 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
 #if W9_PROBE & 2                      // probe build: no LDS-DMA - the fragments go through registers (slow; an aggressor only)
             if (inst < n_inst) dst[inst * 64 + lane] = wcb[inst * 64 + lane];
 #else
-            if (inst < n_inst) __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
+            if (inst < n_inst) {
+                if constexpr (PIPE) w9_dma16(wcb + inst * 64 + lane, dst + inst * 64);
+                else __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
+            }
 #endif
         }
     };
@@ -201,6 +226,96 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         __syncthreads();
         if (cb + 1 < n_cb) { prefetch_w(cb + 1); if (!FIRST) prefetch_x(cb + 1, pxr); }
         const f16x8* s_w = (cb & 1) ? s_w1 : s_w0;
+        if constexpr (PIPE) {
+        // Fragment reads run AHEAD of the MFMAs that consume them (the compiler's own schedule drained lgkmcnt to 0 in front of every
+        // group of 12 MFMAs: six exposed LDS round trips per stage and wave).  A unit = 12 MFMAs of one row tile m of one k-step; the
+        // A fragments (2 per unit) are double-buffered and requested one unit ahead; the B fragments of the next k-step replace the
+        // current ones pair by pair inside the last unit of a k-step, behind the MFMAs that read them last.  sched_barriers pin the
+        // order; the waits are the compiler's counted lgkmcnt(N).  Every accumulator still receives its products in the same order
+        // as before (k-step by k-step: ah*bl, al*bh, ah*bh), so the output is bit-identical.
+        const bool third = (((cb & 3) == 3) || cb == n_cb - 1) && !(W9_PROBE & 0x10);
+        f16x8 bh[4], bl[4], ah[2], al[2];
+        auto ld_b = [&](int ks, int q) {
+            const int off = b_tap[ks] + ((q >> 1) * W9_RS + (q & 1) * 16) * W9_CB;
+            bh[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+            bl[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+            if (ROWX) {
+                const int tap = 4 * ks + g;
+                const _Float16 f = ac_rowx_frag_factor(s_ex, 2 * wave + (q >> 1), tap / 3); bh[q] *= (f16x8)f; bl[q] *= (f16x8)f;
+            }
+        };
+        auto ld_a = [&](int ks, int m, int slot) {
+            ah[slot] = s_w[((ks * 2 + 0) * W9_MT + m) * 64 + lane];
+            al[slot] = s_w[((ks * 2 + 1) * W9_MT + m) * 64 + lane];
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ld_b(0, q);
+        ld_a(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int m = 0; m < W9_MT; ++m) {
+                const int slot = (ks * W9_MT + m) & 1;
+                const bool last_m = m == W9_MT - 1;
+                if (!last_m) ld_a(ks, m + 1, slot ^ 1);
+                else if (ks == 0) ld_a(1, 0, slot ^ 1);
+                else if (third) ld_a(2, 0, slot ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (last_m && ks == 0) {
+#pragma unroll
+                    for (int qp = 0; qp < 4; qp += 2) {
+#pragma unroll
+                        for (int q = qp; q < qp + 2; ++q) acc[m][q] = w9_mfma(ah[slot], bl[q], acc[m][q]);
+#pragma unroll
+                        for (int q = qp; q < qp + 2; ++q) acc[m][q] = w9_mfma(al[slot], bh[q], acc[m][q]);
+#pragma unroll
+                        for (int q = qp; q < qp + 2; ++q) acc[m][q] = w9_mfma(ah[slot], bh[q], acc[m][q]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ld_b(1, qp); ld_b(1, qp + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    if (last_m && ks == 1 && !(W9_PROBE & 0x10)) {
+                        // tap 8 (dy = dx = 2) of this stage goes into lane group cb & 3 of the carried fragments; requested in front
+                        // of the stage's last unit so that a shared step that follows finds them landed
+                        if (g == (cb & 3)) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int off = b_lane + ((2 + (q >> 1)) * W9_RS + 2 + (q & 1) * 16) * W9_CB;
+                                k8h[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
+                                k8l[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
+                                if (ROWX) { const _Float16 f = ac_rowx_frag_factor(s_ex, 2 * wave + (q >> 1), 2); k8h[q] *= (f16x8)f; k8l[q] *= (f16x8)f; }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[m][q] = w9_mfma(ah[slot], bl[q], acc[m][q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[m][q] = w9_mfma(al[slot], bh[q], acc[m][q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[m][q] = w9_mfma(ah[slot], bh[q], acc[m][q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (third) {                     // a trailing group of two stages: lane groups 2-3 meet zero weights
+#pragma unroll
+            for (int m = 0; m < W9_MT; ++m) {
+                const int slot = (2 * W9_MT + m) & 1;
+                if (m + 1 < W9_MT) ld_a(2, m + 1, slot ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[m][q] = w9_mfma(ah[slot], k8l[q], acc[m][q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[m][q] = w9_mfma(al[slot], k8h[q], acc[m][q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[m][q] = w9_mfma(ah[slot], k8h[q], acc[m][q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int tap = 4 * ks + g;
@@ -250,6 +365,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
                 }
             }
         }
+            }
     }
     // ---- epilogue in passes of EP_M row tiles through the LDS tile [co][row][x] -> 128-byte row stores
     float vmax[2] = {0.f, 0.f};          // this wave's two output rows (ty = 2 wave + (q >> 1))
@@ -272,7 +388,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int co = mm * 16 + g * 4 + r;
-                        float v = acc[m][q][r] * us + bias[cob * W9_COB + m0 * 16 + co];
+                        float v = acc[m][q][r] * us + bias[co_base + m0 * 16 + co];
                         if (RELU) v = fmaxf(v, 0.f);
                         vmax[q >> 1] = fmaxf(vmax[q >> 1], fabsf(v));
                         s_out[(co * W9_TH + ty) * W9_OUT_STRIDE + tx] = v;
@@ -281,7 +397,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
             }
         }
         __syncthreads();
-        float* ob = out + ((size_t)b * C_out + (size_t)cob * W9_COB + m0 * 16) * plane;
+        float* ob = out + ((size_t)b * C_out + (size_t)co_base + m0 * 16) * plane;
         for (int e = tid; e < n_m * 16 * W9_TH * (W9_TW / 4); e += 256) {
             const int line = e >> 3, q4 = e & 7;
             const int co = line >> 3, ty = line & 7;
@@ -344,9 +460,79 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     ex_min = __builtin_amdgcn_readfirstlane(ex_min);
     ex_max = __builtin_amdgcn_readfirstlane(ex_max);
     if (ex_min != AC_EX_NONE && ex_max - ex_min > AC_ROWX_SPREAD)
-        w9_tile<MT, RELU, true, FIRST>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0, s_first, C0);
+        w9_tile<MT, RELU, true, FIRST>(x, wpk + (size_t)cob * (C_in / W9_CB) * 3 * W9_KFR, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * W9_COB, b, y0, x0, s_first, C0);
     else
-        w9_tile<MT, RELU, false, FIRST>(x, wpk, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob, b, y0, x0, s_first, C0);
+        w9_tile<MT, RELU, false, FIRST>(x, wpk + (size_t)cob * (C_in / W9_CB) * 3 * W9_KFR, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * W9_COB, b, y0, x0, s_first, C0);
+}
+
+// C_out = 96 n_wide + 48 (levels 2 and 4 of the U-Net: 144, 240): one launch in which the first n_wide channel blocks of every pixel
+// tile run the 96-channel tile and the last one the 48-channel tile (two workgroups per CU either way, the wide kernel's register
+// and LDS budget).  wpk = the wide blocks' fragments followed by the narrow block's (conv_pack.pack_conv3x3_mixed); the blocks of
+// one pixel tile stay neighbours in the XCD-aware order, so the patch crosses the fabric once.
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_mix(const float* __restrict__ x, const f16x8* __restrict__ wpk,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int C_in, int C_out, int H, int W, float w_unscale, int bw,
+                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax) {
+    constexpr int KFR6 = 2 * 6 * 64;
+    constexpr int EP_BYTES = 3 * 16 * W9_TH * W9_OUT_STRIDE * 4;
+    constexpr int K_BYTES = W9_PATCH_BYTES + (2 + 3) * KFR6 * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[K_BYTES > EP_BYTES ? K_BYTES : EP_BYTES];
+    __shared__ int s_ex[W9_PH + 2];
+    const int tid = threadIdx.x;
+    const int n_wide = C_out / 96, n_cob = n_wide + 1;
+    const int tiles_x = W / W9_TW, tiles_y = H / W9_TH;
+    int wi = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int cob = wi % n_cob;
+    int t = wi / n_cob;
+    const int b = t / (tiles_x * tiles_y);
+    t -= b * (tiles_x * tiles_y);
+    const int band = t / (tiles_y * bw);
+    t -= band * (tiles_y * bw);
+    const int y0 = (t / bw) * W9_TH, x0 = (band * bw + t % bw) * W9_TW;
+    if (tid < W9_PH + 2) {
+        const int gy = y0 - 1 + tid;
+        s_ex[tid] = (in_amax && tid < W9_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy]) : AC_EX_NONE;
+    }
+    __syncthreads();
+    int ex_min = AC_EX_NONE, ex_max = -AC_EX_NONE;
+#pragma unroll
+    for (int r = 0; r < W9_PH; ++r) {
+        const int e = s_ex[r];
+        if (e != AC_EX_NONE) { ex_min = e < ex_min ? e : ex_min; ex_max = e > ex_max ? e : ex_max; }
+    }
+    ex_min = __builtin_amdgcn_readfirstlane(ex_min);
+    ex_max = __builtin_amdgcn_readfirstlane(ex_max);
+    const bool rowx = ex_min != AC_EX_NONE && ex_max - ex_min > AC_ROWX_SPREAD;
+    const int n_cb = C_in / W9_CB;
+    if (cob < n_wide) {
+        const f16x8* wb = wpk + (size_t)cob * n_cb * 3 * KFR6;
+        if (rowx) w9_tile<6, RELU, true, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * 96, b, y0, x0, nullptr, 0);
+        else      w9_tile<6, RELU, false, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * 96, b, y0, x0, nullptr, 0);
+    } else {
+        const f16x8* wb = wpk + (size_t)n_wide * n_cb * 3 * KFR6;
+        if (rowx) w9_tile<3, RELU, true, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, n_wide * 96, b, y0, x0, nullptr, 0);
+        else      w9_tile<3, RELU, false, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, n_wide * 96, b, y0, x0, nullptr, 0);
+    }
+}
+
+extern "C" int ac_conv3x3_f16x3_mix(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                                     int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax,
+                                     void* stream) {
+    AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
+    AC_REQUIRE(B > 0 && C_in > 0 && C_in % 16 == 0 && C_out > 96 && C_out % 96 == 48, "C_in % 16 == 0 and C_out = 96 k + 48, k >= 1");
+    AC_REQUIRE(H > 0 && H % W9_TH == 0 && W > 0 && W % W9_TW == 0, "H % 8 == 0 and W % 32 == 0");
+    AC_REQUIRE((long long)H * W < (1LL << 31), "plane too large");
+    const long long nblk = (long long)B * (C_out / 96 + 1) * (H / W9_TH) * (W / W9_TW);
+    AC_REQUIRE(nblk < (1LL << 31), "grid too large");
+    const int tiles_x = W / W9_TW;
+    const int bw = tiles_x % 4 == 0 ? 4 : (tiles_x % 3 == 0 ? 3 : (tiles_x % 2 == 0 ? 2 : 1));
+    dim3 grid((unsigned)nblk), block(256);
+    if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_mix<true>), grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
+    else      hipLaunchKernelGGL((k_conv3x3_f16x3_mix<false>), grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
 }
 
 static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
@@ -371,7 +557,7 @@ static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const fl
     } else if (cob_width == 96) {
         if (relu) W9_GO(6, 2, true, false); else W9_GO(6, 2, false, false);
     } else {
-        if (relu) W9_GO(3, 3, true, false); else W9_GO(3, 3, false, false);
+        if (relu) W9_GO(3, W9_S8_OCC, true, false); else W9_GO(3, W9_S8_OCC, false, false);
     }
 #undef W9_GO
     AC_LAUNCH_CHECK();

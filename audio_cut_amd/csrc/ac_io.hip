@@ -1,9 +1,10 @@
 // Loader / exporter kernels.
 //  * ac_resample_poly: rational-rate polyphase FIR resampling of a resident track (the loader's 48 kHz -> 44.1 kHz and
 //    the VAD's 44.1 kHz -> 16 kHz, `audio_processor.py:45-49`, `vocal_pause_detector.py:189`).  The reference's
-//    resampler is soxr_hq through librosa, which is not available offline, so the parity definition of this row is
-//    scipy.signal.resample_poly(x, up, down) (Kaiser(5.0) windowed sinc, half length 10 * max(up, down), zero padding),
-//    whose filter the host designs with the very scipy calls and hands over already scaled and front-padded.
+//    resampler is soxr_hq through librosa; libsoxr's coefficients are not available offline, so the host designs a low-pass to
+//    soxr's published HQ specification (pass band to 0.9136 of the lower Nyquist, stop band from it, 126 dB: _native.py
+//    `_resample_filter`) and hands it over in scipy.signal.resample_poly's framing (scaled by `up`, front-padded for alignment,
+//    zero extension) as polyphase rows (ac_common.h `ac_polyphase_dot`).
 //  * ac_pack_pcm24: float32 [-1, 1] -> little-endian 24-bit PCM exactly as soundfile.write(subtype="PCM_24") produces it
 //    (`audio_export.py:109-111`).  python-soundfile switches libsndfile's clipping on (SFC_SET_CLIPPING), so the conversion
 //    is libsndfile pcm.c f2let_clip_array: s = x * 2^31 in float32; s >= 2^31 - 1 -> 0x7FFFFF, s <= -2^31 -> 0x800000,
@@ -12,28 +13,21 @@
 #include "ac_common.h"
 
 __global__ __launch_bounds__(256) void k_resample_poly(const float* __restrict__ x, int64_t n, int up, int down,
-                                                       const float* __restrict__ h, int64_t hlen, int64_t n_pre_remove,
+                                                       const float* __restrict__ hp, int tpp, int64_t n_pre_remove,
                                                        float* __restrict__ out, int64_t n_out) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= n_out) return;
-    // y_full[M] = sum_q h[M * down - q * up] x[q], M = m + n_pre_remove
-    const int64_t i = (m + n_pre_remove) * (int64_t)down;
-    int64_t q_hi = i / up;                               // h index >= 0
-    if (q_hi > n - 1) q_hi = n - 1;
-    int64_t q_lo = (i - hlen + 1 + up - 1) / up;         // h index < hlen  (ceil division; i - hlen + 1 may be negative)
-    if (i - hlen + 1 <= 0) q_lo = 0;
-    double acc = 0.0;
-    for (int64_t q = q_lo; q <= q_hi; ++q) acc += (double)h[i - q * up] * (double)x[q];
-    out[m] = (float)acc;
+    out[m] = ac_polyphase_dot(x, n, hp, up, tpp, (m + n_pre_remove) * (int64_t)down);
 }
 
-extern "C" int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* h, int64_t hlen,
+extern "C" int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* hp, int64_t hlen,
                                  int64_t n_pre_remove, float* out, int64_t n_out, void* stream) {
-    AC_REQUIRE(ctx && x && h && out, "null pointer");
+    AC_REQUIRE(ctx && x && hp && out, "null pointer");
     AC_REQUIRE(n > 0 && up > 0 && down > 0 && hlen > 0 && n_pre_remove >= 0 && n_out > 0, "sizes must be positive");
+    AC_REQUIRE(hlen % up == 0 && hlen / up < (1LL << 31), "hp is [up][hlen / up] polyphase rows");
     AC_REQUIRE((n_out + 255) / 256 < (1LL << 31), "output too long");
-    hipLaunchKernelGGL(k_resample_poly, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, up, down, h, hlen,
-                       n_pre_remove, out, n_out);
+    hipLaunchKernelGGL(k_resample_poly, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, up, down, hp,
+                       (int)(hlen / up), n_pre_remove, out, n_out);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

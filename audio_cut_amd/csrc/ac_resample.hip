@@ -22,6 +22,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define RS_NT 3
 #define RS_BFRAGS (2 * (RS_BN / 16) * 64)          // 768 16-byte weight fragments per stage
 #define RS_B_ITERS (RS_BFRAGS / 256)               // 3
+#ifndef RS_SKIP_AHEAD
+#define RS_SKIP_AHEAD 1            // up: strips of the skip tensor requested ahead of the strip being written (1 .. RS_MT - 1; RS_MT = all at once)
+#endif
 
 __device__ inline unsigned rs_pack_hi(float a, float b, unsigned& lo_out, float s) {
     const float ca = fminf(fmaxf(a * s, -65504.f), 65504.f), cb = fminf(fmaxf(b * s, -65504.f), 65504.f);
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
         float* so = s_out + wave * 16 * OSTRIDE_UP;
         const int W2 = 2 * W;
         const size_t plane_out = (size_t)4 * P;
-        float4 sk[2][3];
+        constexpr int SKN = RS_SKIP_AHEAD >= RS_MT ? RS_MT : RS_SKIP_AHEAD + 1;      // ring of skip strips in registers
+        float4 sk[SKN][3];
         auto out_offset = [&](int m, int i, int& nn) -> size_t {
             const int e = lane + 64 * i;                   // 192 float4 per strip: (co_dy = e >> 3) in 0..23, m pair = e & 7
             const int cd = e >> 3, mp = e & 7;
@@ -234,7 +238,9 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
         };
         if (skip) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { int nn; sk[0][i] = *reinterpret_cast<const float4*>(skip + out_offset(0, i, nn)); }
+            for (int m = 0; m < (RS_SKIP_AHEAD < RS_MT ? RS_SKIP_AHEAD : RS_MT); ++m)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { int nn; sk[m % SKN][i] = *reinterpret_cast<const float4*>(skip + out_offset(m, i, nn)); }
         }
         // the 64 pixels of this wave lie in at most two input rows (W >= 64): row_a and row_a + 1, the second from pixel `bnd` on.
         // Their two scales are wave-uniform; the four output maxima (2 input rows x dy) are carried across the strips.
@@ -252,9 +258,9 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
             for (int n = 0; n < RS_NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) so[(g * 4 + r) * OSTRIDE_UP + n * 16 + px] = acc[m][n][r];
-            if (skip && m + 1 < RS_MT) {
+            if (skip && m + RS_SKIP_AHEAD < RS_MT) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { int nn; sk[(m + 1) & 1][i] = *reinterpret_cast<const float4*>(skip + out_offset(m + 1, i, nn)); }
+                for (int i = 0; i < 3; ++i) { int nn; sk[(m + RS_SKIP_AHEAD) % SKN][i] = *reinterpret_cast<const float4*>(skip + out_offset(m + RS_SKIP_AHEAD, i, nn)); }
             }
             __builtin_amdgcn_wave_barrier();
             float vmax[2] = {0.f, 0.f};          // output rows 2 yy (dy = 0) and 2 yy + 1 of this lane's input pixel pair
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                 const float2 a1 = *reinterpret_cast<const float2*>(&so[(2 * mp + 1) * OSTRIDE_UP + nn]);   // pixel 2mp+1: dx 0, 1
                 float4 v = make_float4(fmaxf(a0.x * unscale + bv, 0.f), fmaxf(a0.y * unscale + bv, 0.f),
                                        fmaxf(a1.x * unscale + bv, 0.f), fmaxf(a1.y * unscale + bv, 0.f));
-                if (skip) { const float4 q = sk[m & 1][i]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+                if (skip) { const float4 q = sk[m % SKN][i]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
                 *reinterpret_cast<float4*>(out + o) = v;
                 vmax[dy] = fmaxf(fmaxf(vmax[dy], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }

@@ -25,12 +25,12 @@
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Segmented polyphase resampling: ac_resample_poly for S independent segments in one launch.  Output m of segment s is
-// sum_q h[(m + n_pre_remove) * down - q * up] x[in_off[s] + q] over the segment's own samples only (zero extension at its
-// edges, as scipy.signal.resample_poly on the segment alone); written at out[out_off[s] + m], m < out_len[s].
+// sum_q hfull[(m + n_pre_remove) * down - q * up] x[in_off[s] + q] over the segment's own samples only (zero extension at its
+// edges, as scipy.signal.resample_poly on the segment alone; taps as polyphase rows, ac_common.h); written at out[out_off[s] + m], m < out_len[s].
 __global__ __launch_bounds__(256) void k_resample_poly_seg(const float* __restrict__ x, const int64_t* __restrict__ in_off,
                                                            const int64_t* __restrict__ in_len, const int64_t* __restrict__ out_off,
                                                            const int64_t* __restrict__ out_len, int n_seg, int up, int down,
-                                                           const float* __restrict__ h, int64_t hlen, int64_t n_pre_remove,
+                                                           const float* __restrict__ hp, int tpp, int64_t n_pre_remove,
                                                            float* __restrict__ out, int64_t n_work) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;           // index over the concatenation of the segments' outputs
     if (g >= n_work) return;
@@ -44,14 +44,7 @@ __global__ __launch_bounds__(256) void k_resample_poly_seg(const float* __restri
     if (m >= out_len[lo]) return;                                         // bucket padding: stays zero
     const int64_t n = in_len[lo];
     const float* xs = x + in_off[lo];
-    const int64_t i = (m + n_pre_remove) * (int64_t)down;
-    int64_t q_hi = i / up;
-    if (q_hi > n - 1) q_hi = n - 1;
-    int64_t q_lo = (i - hlen + 1 + up - 1) / up;
-    if (i - hlen + 1 <= 0) q_lo = 0;
-    double acc = 0.0;
-    for (int64_t q = q_lo; q <= q_hi; ++q) acc += (double)h[i - q * up] * (double)xs[q];
-    out[g] = (float)acc;
+    out[g] = ac_polyphase_dot(xs, n, hp, up, tpp, (m + n_pre_remove) * (int64_t)down);
 }
 
 extern "C" int ac_resample_poly_segments(ac_ctx* ctx, const float* x, const int64_t* in_off, const int64_t* in_len,
@@ -60,9 +53,10 @@ extern "C" int ac_resample_poly_segments(ac_ctx* ctx, const float* x, const int6
                                          void* stream) {
     AC_REQUIRE(ctx && x && in_off && in_len && out_off && out_len && h && out, "null pointer");
     AC_REQUIRE(n_seg > 0 && up > 0 && down > 0 && hlen > 0 && n_pre_remove >= 0 && n_out_total > 0, "sizes must be positive");
+    AC_REQUIRE(hlen % up == 0 && hlen / up < (1LL << 31), "h is [up][hlen / up] polyphase rows");
     AC_REQUIRE((n_out_total + 255) / 256 < (1LL << 31), "output too long");
     hipLaunchKernelGGL(k_resample_poly_seg, dim3((unsigned)((n_out_total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, in_off, in_len,
-                       out_off, out_len, n_seg, up, down, h, hlen, n_pre_remove, out, n_out_total);
+                       out_off, out_len, n_seg, up, down, h, (int)(hlen / up), n_pre_remove, out, n_out_total);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

@@ -23,6 +23,7 @@ from __future__ import annotations
 import abc
 import logging
 import os
+import contextlib
 import time
 from dataclasses import dataclass
 from pathlib import Path
@@ -176,12 +177,17 @@ class MDX23HipBackend(IVocalSeparatorBackend):
 
     # -- batched fast path ------------------------------------------------------------------------
     def separate_track(self, track_dev: torch.Tensor, sr: int, plans: Sequence[ChunkPlan],
-                       timings: Optional[Dict[str, float]] = None, defer_sync: bool = False, before_launch=None) -> TrackSeparation:
+                       timings: Optional[Dict[str, float]] = None, defer_sync: bool = False, before_launch=None,
+                       unet_stream=None, after_launch=None) -> TrackSeparation:
         """All chunks of a resident track: STFT -> U-Net -> iSTFT -> stem assembly + OLA, no host bounce.
         Everything is queued on the current stream without a host synchronisation; `defer_sync=True` returns at once
         (the caller overlaps host work and calls `result.finish()` later), otherwise the timings are read before returning.
         `before_launch` is called after the index tables are on the device and before the first kernel is queued
-        (`batch.TrackPipeline` waits there for the previous track's U-Net to leave the GPU)."""
+        (`batch.TrackPipeline` waits there for the previous track's U-Net to leave the GPU).
+        `unet_stream`: queue the whole separation on THAT stream instead of the current one (the current stream waits for its
+        end); `batch.TrackPipeline` gives every worker the same one, so the separations of consecutive tracks are ordered by
+        the stream itself and the next one can be queued while this one still runs - `after_launch` is then called as soon as
+        everything is queued (the pipeline's gate only has to keep two tracks' launches from interleaving)."""
         hip = self.hip
         net = self.net
         n = int(track_dev.numel())
@@ -210,10 +216,56 @@ class MDX23HipBackend(IVocalSeparatorBackend):
         d_base = hip.to_device(np.asarray(base, np.int32))
         offsets = np.concatenate(([0], np.cumsum([r[1] - r[0] for r in ranges]))).astype(np.int64)
         d_offsets = hip.to_device(offsets[:-1])
-        wave = torch.empty((n_items, 2, ITEM_LEN), dtype=torch.float32, device=hip.device)
         step = max(1, self.max_items_per_forward)
+        caller_stream = torch.cuda.current_stream(hip.device)
+        if unet_stream is not None:
+            tables_up = torch.cuda.Event()
+            tables_up.record(caller_stream)
         if before_launch is not None:
             before_launch()
+        if unet_stream is not None:
+            unet_stream.wait_event(tables_up)
+            track_dev.record_stream(unet_stream)
+            for t in (d_cs, d_cl, d_wi, d_chunk_start, d_chunk_len, d_es, d_ee, d_base, d_offsets):
+                t.record_stream(unet_stream)
+        with (torch.cuda.stream(unet_stream) if unet_stream is not None else contextlib.nullcontext()):
+            sep_out = self._queue_separation(track_dev, n_items, step, timings, ranges, offsets,
+                                             (d_cs, d_cl, d_wi, d_chunk_start, d_chunk_len, d_es, d_ee, d_base, d_offsets))
+            if unet_stream is not None:
+                queued = torch.cuda.Event()
+                queued.record()
+        wave, vocal, inst, chunk_vocal, events = sep_out
+        if unet_stream is not None:
+            if after_launch is not None:
+                after_launch()
+            caller_stream.wait_event(queued)
+            for t in (wave, vocal, inst, chunk_vocal):
+                t.record_stream(caller_stream)
+        n_ranges = len(ranges)
+
+        def finish() -> None:      # one synchronisation for the whole track, after everything has been queued
+            t_stft = t_net = t_istft = 0.0
+            if events:
+                events[-1][3].synchronize()
+                for ev in events:
+                    t_stft += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_istft += ev[2].elapsed_time(ev[3])
+            self._perf["chunks"] += float(n_ranges)
+            self._perf["compute_ms"] += t_stft + t_net + t_istft
+            self._perf["max_alloc_bytes"] = max(self._perf["max_alloc_bytes"], float(torch.cuda.max_memory_allocated(hip.device)))
+            if timings is not None:
+                timings.update({"stft_ms": t_stft, "unet_ms": t_net, "istft_ms": t_istft, "n_items": float(n_items)})
+
+        if not defer_sync:
+            finish()
+        return TrackSeparation(vocal, inst, chunk_vocal, [int(o) for o in offsets[:-1]], ranges, n_items,
+                               finish if defer_sync else None)
+
+    def _queue_separation(self, track_dev, n_items, step, timings, ranges, offsets, tables):
+        """Queues STFT -> U-Net -> iSTFT of every sub-batch and the stem assembly on the CURRENT stream; no host synchronisation."""
+        hip = self.hip
+        net = self.net
+        d_cs, d_cl, d_wi, d_chunk_start, d_chunk_len, d_es, d_ee, d_base, d_offsets = tables
+        wave = torch.empty((n_items, 2, ITEM_LEN), dtype=torch.float32, device=hip.device)
         events: List[List[torch.cuda.Event]] = []     # per sub-batch: [before stft, before net, before istft, after istft]
         for a in range(0, n_items, step):
             b = min(n_items, a + step)
@@ -239,24 +291,7 @@ class MDX23HipBackend(IVocalSeparatorBackend):
             vocal, inst = other, vocal_like
             chunk_mix = torch.cat([track_dev[cs:ce] for cs, ce, _, _ in ranges])
             chunk_vocal = chunk_mix - chunk_vocal
-        n_ranges = len(ranges)
-
-        def finish() -> None:      # one synchronisation for the whole track, after everything has been queued
-            t_stft = t_net = t_istft = 0.0
-            if events:
-                events[-1][3].synchronize()
-                for ev in events:
-                    t_stft += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_istft += ev[2].elapsed_time(ev[3])
-            self._perf["chunks"] += float(n_ranges)
-            self._perf["compute_ms"] += t_stft + t_net + t_istft
-            self._perf["max_alloc_bytes"] = max(self._perf["max_alloc_bytes"], float(torch.cuda.max_memory_allocated(hip.device)))
-            if timings is not None:
-                timings.update({"stft_ms": t_stft, "unet_ms": t_net, "istft_ms": t_istft, "n_items": float(n_items)})
-
-        if not defer_sync:
-            finish()
-        return TrackSeparation(vocal, inst, chunk_vocal, [int(o) for o in offsets[:-1]], ranges, n_items,
-                               finish if defer_sync else None)
+        return wave, vocal, inst, chunk_vocal, events
 
     # -- reference-shaped per-chunk call ----------------------------------------------------------
     def infer_chunk(self, mix_chunk: np.ndarray, **kwargs) -> SeparationOutputs:

@@ -270,6 +270,9 @@ def main() -> None:
                     help="tracks in flight per GPU (audio_cut_amd.batch.TrackPipeline): 1 = strictly one after the other")
     ap.add_argument("--no-separation-gate", action="store_true",
                     help="experiment: let the U-Nets of the tracks in flight run concurrently (default: one separation on the GPU at a time)")
+    ap.add_argument("--shared-unet-stream", type=int, default=1,
+                    help="1 (default): every worker queues its separation on the pipeline's one U-Net stream, the gate only serialises the "
+                         "queueing; 0: each worker on its own stream, the gate held until the U-Net has left the GPU (round 2's scheme)")
     ap.add_argument("--write-golden", default=None, metavar="PATH",
                     help="(c3, N = 1) write the per-track SHA-1 table of this run to PATH (committed as tests/golden/c3_n1_sha1.json)")
     args = ap.parse_args()
@@ -347,9 +350,10 @@ def main() -> None:
     splitters = [SeamlessSplitter(sr, separator=EnhancedVocalSeparator(sr, backend=backend, vad_inference_fn=vad_fn)) for _ in range(depth)]
     pipeline = batch.TrackPipeline(splitters, device)
     gate = pipeline.separation_gate if (depth > 1 and not args.no_separation_gate) else None
+    unet_stream = pipeline.unet_stream if (depth > 1 and args.shared_unet_stream and gate is not None) else None
 
     def job_for(mix, mix_dev):
-        return lambda sp: sp.split_track(mix, mode=mode, audio_dev=mix_dev, separation_gate=gate)
+        return lambda sp: sp.split_track(mix, mode=mode, audio_dev=mix_dev, separation_gate=gate, unet_stream=unet_stream)
 
     # every timed track is generated and made resident in HBM before the clock starts (BASELINE contract); warm-up tracks are
     # tracks of their own (seeds 50, 51, ...) so nothing of a timed track has been seen before
@@ -461,7 +465,7 @@ def main() -> None:
                 "track_seconds": track_s, "chunks_per_track": res["gpu_meta"].get("gpu_pipeline_chunks"),
                 "unet_items_per_track": items // max(1, steps),
                 "items_per_forward": args.items_per_forward, "tracks_per_gpu": steps, "sharding": "track-per-rank (assign_tracks, LPT)",
-                "track_seeds": [d["seed"] for d in all_summaries], "pipeline_depth": depth,
+                "track_seeds": [d["seed"] for d in all_summaries], "pipeline_depth": depth, "shared_unet_stream": unet_stream is not None,
                 "real_time_factor": round(total_audio / elapsed / world, 2),
             },
             "roofline": roofline_conv(probe, conv_ms, conv_flops, elapsed),

@@ -29,7 +29,7 @@ extern "C" {
 #define AC_E_HIP (-2)       /* a HIP runtime call failed */
 #define AC_E_NOMEM (-3)
 
-#define AC_ABI_VERSION 3
+#define AC_ABI_VERSION 4
 
 typedef struct ac_ctx ac_ctx;
 
@@ -284,11 +284,13 @@ int ac_segment_sumsq_peak(ac_ctx* ctx, const float* x, int64_t n, const int64_t*
 
 /* ---- loader / exporter ----------------------------------------------------------- */
 
-/* Rational-rate polyphase resampling = scipy.signal.resample_poly(x, up, down) (the offline parity definition of the
- * loader's `librosa.load(sr=44100)` at audio_processor.py:45-49 and the VAD's 16 kHz resample at
- * vocal_pause_detector.py:189, whose soxr_hq filter is not available).  h [hlen] float32 = firwin(...) * up with the
- * n_pre_pad leading zeros scipy adds; out[m] = sum_q h[(m + n_pre_remove) * down - q * up] x[q], float64 accumulation. */
-int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* h, int64_t hlen, int64_t n_pre_remove,
+/* Rational-rate polyphase FIR resampling in scipy.signal.resample_poly's framing (zero extension, output 0 aligned with input 0,
+ * ceil(n * up / down) outputs): the loader's `librosa.load(sr=44100)` at audio_processor.py:45-49 and the VAD's 16 kHz resample at
+ * vocal_pause_detector.py:189, both librosa's default soxr_hq.  libsoxr's coefficients are not available offline; the host designs
+ * the low-pass to soxr's published HQ specification.  out[m] = sum_q hfull[(m + n_pre_remove) * down - q * up] x[q],
+ * float64 accumulation, where hfull = taps * up behind the n_pre_pad leading zeros of resample_poly; it arrives as polyphase rows
+ * hp [up][hlen / up] float32, hp[p][t] = hfull[p + t * up] (zero beyond hfull's end; hlen % up == 0).  (ABI 4: rows; ABI <= 3 took hfull.) */
+int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* hp, int64_t hlen, int64_t n_pre_remove,
                      float* out, int64_t n_out, void* stream);
 /* float32 -> little-endian PCM_24 as soundfile.write(subtype="PCM_24") writes it (vocal_smart_splitter/utils/audio_export.py:109-111):
  * libsndfile's clipping conversion (python-soundfile sets SFC_SET_CLIPPING): lrintf(x * 2^31) >> 8, saturating at
@@ -316,6 +318,12 @@ int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, cons
  * conv_pack.pack_conv3x3_w96(w, cob=48)): the layers ac_conv3x3_f16x3_w96 cannot take. */
 int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                         int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
+/* The same convolution for C_out = 96 k + 48 (k >= 1: the U-Net's levels 2 and 4, C = 144 / 240) in ONE launch: the first k channel
+ * blocks of every pixel tile run the 96-channel workgroup tile of ac_conv3x3_f16x3_w96, the last one the 48-channel tile of
+ * ac_conv3x3_f16x3_s8 (identical arithmetic and summation order: bit-identical to either).  w_packed = the wide blocks' fragments
+ * followed by the narrow block's, one common weight scale (conv_pack.pack_conv3x3_mixed). */
+int ac_conv3x3_f16x3_mix(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
+                         int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
 
 /* ---- Silero VAD (vocal_pause_detector.py:175-296 behind silero_chunk_vad.py:56-117) ----------------------- */
 

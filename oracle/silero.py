@@ -70,8 +70,8 @@ def silero_probs(weights: Weights, audio16k: np.ndarray) -> np.ndarray:
 
 
 def resample_to_16k(audio: np.ndarray, sr: int) -> np.ndarray:
-    g = int(np.gcd(SR16, int(sr)))
-    return scipy.signal.resample_poly(np.asarray(audio, dtype=np.float32), SR16 // g, int(sr) // g).astype(np.float32)
+    from . import resample as RS            # soxr-HQ-specification low-pass (librosa.resample's default res_type), oracle/resample.py
+    return RS.resample(np.asarray(audio, dtype=np.float32), SR16, int(sr))
 
 
 def detect_speech_timestamps(audio: np.ndarray, sr: int, weights: Weights, adaptive=None) -> List[Dict[str, int]]:

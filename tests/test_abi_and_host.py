@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
         assert name in _native.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_native.SIGNATURES) == set(names)
-    assert lib.ac_abi_version() == 3
+    assert lib.ac_abi_version() == 4
 
 
 def test_size_helpers_need_no_gpu(lib):
@@ -254,3 +254,29 @@ def test_library_has_no_packed_float32_instructions(tmp_path):
         bad += [ln.strip() for ln in asm.splitlines() if "v_pk_mov_b32" in ln]
         assert not bad, f"{len(bad)} packed-float32 instructions in {part.name}, e.g. {bad[:3]}"
     assert n_inst > 1000          # the disassembly really is the kernels (the conv / GEMM MFMA streams are in there)
+
+
+def test_resampling_filter_meets_the_soxr_hq_specification():
+    """the reference resamples with librosa's default soxr_hq (audio_processor.py:44-48, vocal_pause_detector.py:189).
+    libsoxr's coefficients cannot be pinned offline; its published HQ specification can: pass band flat to 0.9136 of the lower
+    Nyquist frequency, stop band from that Nyquist on, >= 120 dB (20 bits).  The oracle's float64 design (oracle/resample.py, explicit
+    Kaiser formulas) meets it, and the product's (audio_cut_amd/_native.py, scipy's kaiserord + firwin, float32) is the same filter."""
+    from audio_cut_amd._native import Context
+    from oracle import resample as ORS
+    assert abs(ORS.SOXR_HQ_PASSBAND_END - 0.91363) < 1e-5 and abs(Context.SOXR_HQ_PASSBAND_END - ORS.SOXR_HQ_PASSBAND_END) < 1e-12
+    for up, down in ((147, 160), (160, 441)):            # 48 kHz -> 44.1 kHz (loader), 44.1 kHz -> 16 kHz (Silero input)
+        h = ORS.soxr_hq_lowpass(up, down)
+        rate = max(up, down)
+        assert h.size % 2 == 1 and np.array_equal(h, h[::-1]) and abs(float(np.sum(h)) - 1.0) < 1e-12
+        pb = ORS.response_db(h, np.linspace(0.0, ORS.SOXR_HQ_PASSBAND_END, 1501) / rate)
+        assert float(np.max(np.abs(pb))) < 1e-4                                     # flat (measured 5e-6 dB)
+        sb = ORS.response_db(h, np.linspace(1.0, 6.0, 6001) / rate)
+        assert float(np.max(sb)) < -120.0                                           # measured -124.5 dB at the edge, < -133 dB from 1.02 on
+        hp, n_pre_remove = Context._resample_filter(up, down)
+        n_pre_pad = hp.size - h.size
+        assert n_pre_pad == down - ((h.size - 1) // 2) % down and n_pre_remove == ((h.size - 1) // 2 + n_pre_pad) // down
+        assert not hp[:n_pre_pad].any()
+        assert float(np.max(np.abs(hp[n_pre_pad:].astype(np.float64) - h * up))) < 1e-7 * float(np.max(h * up))
+    x = np.random.default_rng(0).standard_normal(3000).astype(np.float32)
+    assert ORS.resample(x, 16000, 44100).shape == (-(-3000 * 160 // 441),)          # librosa / resample_poly length rule
+    assert np.array_equal(ORS.resample(x, 5, 5), x)

@@ -53,13 +53,15 @@ def test_segment_exporter_names(tmp_path):
 
 
 @pytest.mark.gpu
-def test_resample_poly_kernel_vs_scipy(hip_ctx):
-    import scipy.signal
+def test_resample_poly_kernel_vs_oracle(hip_ctx):
+    """ac_resample_poly with the product's soxr-HQ-specification filter against the oracle's independently designed float64 filter
+    applied by scipy.signal.resample_poly (oracle/resample.py)."""
+    from oracle import resample as ORS
     rng = np.random.default_rng(0)
     t = np.arange(48000 * 2) / 48000.0
     x = (0.4 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 9000 * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
     for up, down in ((44100, 48000), (16000, 44100), (2, 1), (3, 7)):
-        ref = scipy.signal.resample_poly(x, up, down)
+        ref = ORS.resample(x, up, down)
         got = hip_ctx.resample_poly(hip_ctx.to_device(x), up, down).cpu().numpy()
         assert got.shape == ref.shape
         assert float(np.max(np.abs(got - ref))) < 2e-6 * max(1.0, float(np.max(np.abs(ref)))), (up, down)

@@ -444,10 +444,14 @@ def test_track_pipeline_matches_sequential_processing(hip_ctx):
     ref = [solo.split_track(t) for t in tracks]
     pipe = batch.TrackPipeline([mk(), mk()], hip_ctx.device)
     got = pipe.run([(lambda sp, t=t: sp.split_track(t, separation_gate=pipe.separation_gate)) for t in tracks])
-    for i, (a, b) in enumerate(zip(ref, got)):
-        assert a["sample_boundaries"] == b["sample_boundaries"], i
-        assert a["cuts_samples"] == b["cuts_samples"] and a["segment_vocal_flags"] == b["segment_vocal_flags"], i
+    # ... and with every worker's separation queued on the pipeline's ONE U-Net stream (the gate only serialises the queueing)
+    got_shared = pipe.run([(lambda sp, t=t: sp.split_track(t, separation_gate=pipe.separation_gate, unet_stream=pipe.unet_stream)) for t in tracks])
+    for i, (a, b, c) in enumerate(zip(ref, got, got_shared)):
+        assert a["sample_boundaries"] == b["sample_boundaries"] == c["sample_boundaries"], i
+        assert a["cuts_samples"] == b["cuts_samples"] == c["cuts_samples"], i
+        assert a["segment_vocal_flags"] == b["segment_vocal_flags"] == c["segment_vocal_flags"], i
         assert np.array_equal(a["vocal_track"], b["vocal_track"]), i          # same kernels, same order inside a track: bit-identical stems
+        assert np.array_equal(a["vocal_track"], c["vocal_track"]), i
     summaries = [batch.summarize(i, r["sample_boundaries"], len(t) / SR) for i, (r, t) in enumerate(zip(got, tracks))]
     assert [s["track"] for s in batch.gather_summaries(summaries)] == list(range(6))
     with pytest.raises(ValueError):                                           # a failing job surfaces, the pipeline does not hang
@@ -499,11 +503,11 @@ def test_c5_long_form_end_to_end_against_oracle_fixture(hip_ctx, golden_dir):
 
 def test_c5_loader_leg_48k_stereo_at_full_length(hip_ctx):
     """The load leg of BASELINE configs[4] at full size: 30 min of 48 kHz stereo -> channel mean -> ac_resample_poly 147/160 on
-    the device (the reference: librosa.load(sr=44100, mono=True), `audio_processor.py:45-49`; its soxr_hq filter cannot be pinned
-    offline, so this row's parity definition is scipy.signal.resample_poly - see DESIGN.md).  Properties at 86.4 M input samples:
-    exact output length, agreement with scipy on windows spread over the track (the FIR is local), exact homogeneity under a
+    the device (the reference: librosa.load(sr=44100, mono=True), `audio_processor.py:45-49`; its soxr_hq coefficients cannot be pinned
+    offline, so this row's parity definition is the oracle's filter to soxr's published HQ specification, oracle/resample.py - see DESIGN.md).  Properties at 86.4 M input samples:
+    exact output length, agreement with the oracle on windows spread over the track (the FIR is local), exact homogeneity under a
     power-of-two gain, and section energies preserved (the source has < 0.1 % of its energy above 20 kHz)."""
-    import scipy.signal
+    from oracle import resample as ORS
     st = signals.c5_long_form(1800.0, seed=5, sr=48000, stereo=True)
     assert st.shape == (2, 1800 * 48000)
     mono = np.mean(st, axis=0).astype(np.float32)
@@ -518,7 +522,7 @@ def test_c5_loader_leg_48k_stereo_at_full_length(hip_ctx):
     for c in [0, len(mono) - 480000] + [int(v) for v in rng.integers(10_000_000, len(mono) - 10_000_000, 6)]:
         c -= c % 160                                     # window starts on a polyphase period: output index = c * 147 / 160 exactly
         lo = max(0, c - 160 * 40); hi = min(len(mono), c + 480000 + 160 * 40)
-        ref = scipy.signal.resample_poly(mono[lo:hi], 147, 160)
+        ref = ORS.resample(mono[lo:hi], 147, 160)
         o0 = c * 147 // 160; r0 = (c - lo) * 147 // 160
         n_cmp = 400000 * 147 // 160
         assert float(np.max(np.abs(yh[o0:o0 + n_cmp] - ref[r0:r0 + n_cmp]))) < 2e-6 * max(1.0, float(np.max(np.abs(ref)))), c
@@ -555,7 +559,8 @@ def test_c3_batch_of_32_tracks_on_one_gpu(hip_ctx, golden_dir):
     for lo in range(0, 32, 8):                       # eight tracks resident at a time
         mixes = [signals.c2_song(240.0, seed=s) for s in seeds[lo:lo + 8]]
         devs = [hip_ctx.to_device(m) for m in mixes]
-        out = pipe.run([(lambda sp, m=m, d=d: sp.split_track(m, audio_dev=d, separation_gate=pipe.separation_gate)) for m, d in zip(mixes, devs)])
+        out = pipe.run([(lambda sp, m=m, d=d: sp.split_track(m, audio_dev=d, separation_gate=pipe.separation_gate, unet_stream=pipe.unet_stream))
+                        for m, d in zip(mixes, devs)])       # bench.py's default scheme: one U-Net stream, the next track queued behind the running one
         for s, m, r in zip(seeds[lo:lo + 8], mixes, out):
             sm = batch.summarize(s, r["sample_boundaries"], 240.0)
             assert sm["boundaries_sha1"] == table[str(s)]["boundaries_sha1"], s
