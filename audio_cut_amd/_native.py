@@ -73,7 +73,6 @@ SIGNATURES = {
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_w96": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_s8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
-    "ac_conv3x3_f16x3_mix": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_first": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, C.c_float, C.c_float,
                                          _P, _P]),
     "ac_tdf_linear_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, C.c_float, _P, _P, _P]),
@@ -622,14 +621,6 @@ class Context:
                          out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The 8-channel-stage conv kernel with 48 output channels per workgroup (`pack_conv3x3_w96(w, cob=48)` weights)."""
         return self._conv3x3(self.lib.ac_conv3x3_f16x3_s8, "conv3x3_f16x3_s8", x, w_packed, bias, c_out, w_unscale, relu, out,
-                             in_amax, out_amax)
-
-    def conv3x3_f16x3_mix(self, x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c_out: int, w_unscale: float = 1.0,
-                          relu: bool = True, out: Optional[torch.Tensor] = None, in_amax: Optional[torch.Tensor] = None,
-                          out_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """C_out = 96 k + 48: 96-channel workgroup tiles for the first k blocks and one 48-channel tile, one launch
-        (`pack_conv3x3_mixed` weights)."""
-        return self._conv3x3(self.lib.ac_conv3x3_f16x3_mix, "conv3x3_f16x3_mix", x, w_packed, bias, c_out, w_unscale, relu, out,
                              in_amax, out_amax)
 
     def conv3x3_f16x3_first(self, spec: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,

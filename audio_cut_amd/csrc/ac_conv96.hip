@@ -465,76 +465,6 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
         w9_tile<MT, RELU, false, FIRST>(x, wpk + (size_t)cob * (C_in / W9_CB) * 3 * W9_KFR, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * W9_COB, b, y0, x0, s_first, C0);
 }
 
-// C_out = 96 n_wide + 48 (levels 2 and 4 of the U-Net: 144, 240): one launch in which the first n_wide channel blocks of every pixel
-// tile run the 96-channel tile and the last one the 48-channel tile (two workgroups per CU either way, the wide kernel's register
-// and LDS budget).  wpk = the wide blocks' fragments followed by the narrow block's (conv_pack.pack_conv3x3_mixed); the blocks of
-// one pixel tile stay neighbours in the XCD-aware order, so the patch crosses the fabric once.
-template <bool RELU>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_f16x3_mix(const float* __restrict__ x, const f16x8* __restrict__ wpk,
-                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                              int C_in, int C_out, int H, int W, float w_unscale, int bw,
-                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax) {
-    constexpr int KFR6 = 2 * 6 * 64;
-    constexpr int EP_BYTES = 3 * 16 * W9_TH * W9_OUT_STRIDE * 4;
-    constexpr int K_BYTES = W9_PATCH_BYTES + (2 + 3) * KFR6 * 16;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[K_BYTES > EP_BYTES ? K_BYTES : EP_BYTES];
-    __shared__ int s_ex[W9_PH + 2];
-    const int tid = threadIdx.x;
-    const int n_wide = C_out / 96, n_cob = n_wide + 1;
-    const int tiles_x = W / W9_TW, tiles_y = H / W9_TH;
-    int wi = blockIdx.x;
-    if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int cob = wi % n_cob;
-    int t = wi / n_cob;
-    const int b = t / (tiles_x * tiles_y);
-    t -= b * (tiles_x * tiles_y);
-    const int band = t / (tiles_y * bw);
-    t -= band * (tiles_y * bw);
-    const int y0 = (t / bw) * W9_TH, x0 = (band * bw + t % bw) * W9_TW;
-    if (tid < W9_PH + 2) {
-        const int gy = y0 - 1 + tid;
-        s_ex[tid] = (in_amax && tid < W9_PH && gy >= 0 && gy < H) ? ac_row_ex(in_amax[(size_t)b * H + gy]) : AC_EX_NONE;
-    }
-    __syncthreads();
-    int ex_min = AC_EX_NONE, ex_max = -AC_EX_NONE;
-#pragma unroll
-    for (int r = 0; r < W9_PH; ++r) {
-        const int e = s_ex[r];
-        if (e != AC_EX_NONE) { ex_min = e < ex_min ? e : ex_min; ex_max = e > ex_max ? e : ex_max; }
-    }
-    ex_min = __builtin_amdgcn_readfirstlane(ex_min);
-    ex_max = __builtin_amdgcn_readfirstlane(ex_max);
-    const bool rowx = ex_min != AC_EX_NONE && ex_max - ex_min > AC_ROWX_SPREAD;
-    const int n_cb = C_in / W9_CB;
-    if (cob < n_wide) {
-        const f16x8* wb = wpk + (size_t)cob * n_cb * 3 * KFR6;
-        if (rowx) w9_tile<6, RELU, true, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * 96, b, y0, x0, nullptr, 0);
-        else      w9_tile<6, RELU, false, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * 96, b, y0, x0, nullptr, 0);
-    } else {
-        const f16x8* wb = wpk + (size_t)n_wide * n_cb * 3 * KFR6;
-        if (rowx) w9_tile<3, RELU, true, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, n_wide * 96, b, y0, x0, nullptr, 0);
-        else      w9_tile<3, RELU, false, false>(x, wb, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, n_wide * 96, b, y0, x0, nullptr, 0);
-    }
-}
-
-extern "C" int ac_conv3x3_f16x3_mix(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                                     int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax,
-                                     void* stream) {
-    AC_REQUIRE(ctx && x && w_packed && bias && out, "null pointer");
-    AC_REQUIRE(B > 0 && C_in > 0 && C_in % 16 == 0 && C_out > 96 && C_out % 96 == 48, "C_in % 16 == 0 and C_out = 96 k + 48, k >= 1");
-    AC_REQUIRE(H > 0 && H % W9_TH == 0 && W > 0 && W % W9_TW == 0, "H % 8 == 0 and W % 32 == 0");
-    AC_REQUIRE((long long)H * W < (1LL << 31), "plane too large");
-    const long long nblk = (long long)B * (C_out / 96 + 1) * (H / W9_TH) * (W / W9_TW);
-    AC_REQUIRE(nblk < (1LL << 31), "grid too large");
-    const int tiles_x = W / W9_TW;
-    const int bw = tiles_x % 4 == 0 ? 4 : (tiles_x % 3 == 0 ? 3 : (tiles_x % 2 == 0 ? 2 : 1));
-    dim3 grid((unsigned)nblk), block(256);
-    if (relu) hipLaunchKernelGGL((k_conv3x3_f16x3_mix<true>), grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
-    else      hipLaunchKernelGGL((k_conv3x3_f16x3_mix<false>), grid, block, 0, (hipStream_t)stream, x, (const f16x8*)w_packed, bias, out, C_in, C_out, H, W, w_unscale, bw, in_amax, out_amax);
-    AC_LAUNCH_CHECK();
-    return AC_OK;
-}
-
 static int w9_launch(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in, int C_out,
                      int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream, int cob_width,
                      const float* w1 = nullptr, const float* b1 = nullptr, int C0 = 0, float amax_gain = 1.f, float amax_offs = 0.f) {

@@ -4,7 +4,7 @@
 //    resampler is soxr_hq through librosa; libsoxr's coefficients are not available offline, so the host designs a low-pass to
 //    soxr's published HQ specification (pass band to 0.9136 of the lower Nyquist, stop band from it, 126 dB: _native.py
 //    `_resample_filter`) and hands it over in scipy.signal.resample_poly's framing (scaled by `up`, front-padded for alignment,
-//    zero extension) as polyphase rows (ac_common.h `ac_polyphase_dot`).
+//    zero extension) as polyphase rows, one wave per output (ac_common.h `ac_polyphase_dot_wave`).
 //  * ac_pack_pcm24: float32 [-1, 1] -> little-endian 24-bit PCM exactly as soundfile.write(subtype="PCM_24") produces it
 //    (`audio_export.py:109-111`).  python-soundfile switches libsndfile's clipping on (SFC_SET_CLIPPING), so the conversion
 //    is libsndfile pcm.c f2let_clip_array: s = x * 2^31 in float32; s >= 2^31 - 1 -> 0x7FFFFF, s <= -2^31 -> 0x800000,
@@ -15,9 +15,11 @@
 __global__ __launch_bounds__(256) void k_resample_poly(const float* __restrict__ x, int64_t n, int up, int down,
                                                        const float* __restrict__ hp, int tpp, int64_t n_pre_remove,
                                                        float* __restrict__ out, int64_t n_out) {
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= n_out) return;
-    out[m] = ac_polyphase_dot(x, n, hp, up, tpp, (m + n_pre_remove) * (int64_t)down);
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * AC_RS_PER_WAVE;      // a wave walks AC_RS_PER_WAVE consecutive outputs
+    for (int64_t m = m0; m < m0 + AC_RS_PER_WAVE && m < n_out; ++m) {
+        const float v = ac_polyphase_dot_wave(x, n, hp, up, tpp, (m + n_pre_remove) * (int64_t)down);
+        if ((threadIdx.x & 63) == 0) out[m] = v;
+    }
 }
 
 extern "C" int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, int down, const float* hp, int64_t hlen,
@@ -25,8 +27,9 @@ extern "C" int ac_resample_poly(ac_ctx* ctx, const float* x, int64_t n, int up, 
     AC_REQUIRE(ctx && x && hp && out, "null pointer");
     AC_REQUIRE(n > 0 && up > 0 && down > 0 && hlen > 0 && n_pre_remove >= 0 && n_out > 0, "sizes must be positive");
     AC_REQUIRE(hlen % up == 0 && hlen / up < (1LL << 31), "hp is [up][hlen / up] polyphase rows");
-    AC_REQUIRE((n_out + 255) / 256 < (1LL << 31), "output too long");
-    hipLaunchKernelGGL(k_resample_poly, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, up, down, hp,
+    const int64_t blocks = (n_out + 4 * AC_RS_PER_WAVE - 1) / (4 * AC_RS_PER_WAVE);
+    AC_REQUIRE(blocks < (1LL << 31), "output too long");
+    hipLaunchKernelGGL(k_resample_poly, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, up, down, hp,
                        (int)(hlen / up), n_pre_remove, out, n_out);
     AC_LAUNCH_CHECK();
     return AC_OK;

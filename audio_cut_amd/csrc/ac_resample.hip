@@ -17,7 +17,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define RS_BM 128
 #define RS_BN 96
 #define RS_BK 32
-#define RS_ASTRIDE 48            // f16 per staged pixel row: 32 used + 16 pad -> 96 bytes (conflict-free for ds_read_b128's four 16-lane groups)
+// Staged A tile [pixel][k] (f16 hi and lo).  The layout and the thread -> (pixel, channel) mapping of the loaders are chosen so that
+// BOTH the staging stores (ds_write_b64: four groups of 16 contiguous lanes, 32 banks) and the fragment reads (ds_read_b128) are
+// conflict-free; round 2's mapping put the 16 lanes of a store group on pixels 4 (up) or 2 (down) rows apart = 384 / 192 bytes =
+// the same bank: 16-way / 8-way conflicts on every staging store, 67-74 % of all LDS cycles (SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE, profiles/r03f_pmc_probe.txt).
+//   down: row stride 96 bytes; a store group = 8 consecutive channel quads of 2 pixel pairs
+//   up:   row stride 112 bytes with odd pixels shifted by 16 bytes; a store group = 8 consecutive channel quads of 2 pixel quads
+#define RS_ASTRIDE_DN 48         // f16 per staged pixel row: 32 used + 16 pad -> 96 bytes
+#define RS_ASTRIDE_UP 56         // 112 bytes (+ 8 f16 for odd pixels: 80 of the 112 used)
 #define RS_MT 4
 #define RS_NT 3
 #define RS_BFRAGS (2 * (RS_BN / 16) * 64)          // 768 16-byte weight fragments per stage
@@ -49,7 +57,8 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
                                                              float* __restrict__ out, int Ci, int Co, int H, int W,
                                                              int n_stage, int n_nblk, int n_mblk, float w_unscale,
                                                              const float* __restrict__ in_amax, float* __restrict__ out_amax) {
-    constexpr int A_BYTES = 2 * RS_BM * RS_ASTRIDE * 2;                      // 20480
+    constexpr int RS_ASTRIDE = MODE ? RS_ASTRIDE_UP : RS_ASTRIDE_DN;
+    constexpr int A_BYTES = 2 * RS_BM * RS_ASTRIDE * 2;                      // 24576 (down) / 28672 (up)
     constexpr int OSTRIDE_UP = 48 + 4;                                       // up: strip [16 m][48 n]
     constexpr int OSTRIDE_DN = 64 + 4;                                       // down: strip [16 n][64 m]
     constexpr int O_BYTES = 4 * 16 * (MODE ? OSTRIDE_UP : OSTRIDE_DN) * 4;
@@ -89,27 +98,29 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
         for (int n = 0; n < RS_NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- A loader state --------------------------------------------------------------------------------------
-    // down: item (pixel pair p = e & 63, channel e >> 6 of the stage's 8), two float4 (dy = 0, 1) = 2 pixels x 4 taps
-    // up:   item (pixel quad q = tid & 31, channel quad tid >> 5 of the stage's 8), four float4 = 4 pixels x 4 channels
+    // down: item e = tid + 256 i: (channel e & 7 of the stage's 8, pixel pair p = e >> 3), two float4 (dy = 0, 1) = 2 pixels x 4 taps
+    // up:   item (channel quad tid & 7 of the stage's 8, pixel quad q = tid >> 3), four float4 = 4 pixels x 4 channels
     constexpr int A_LD = MODE ? 4 : 4;                       // float4 loads per thread per stage (both modes: 4)
     float4 pre_a[A_LD];
     size_t dn_src[2];
     int dn_ci[2], dn_off[2];
+    float dn_s[2] = {1.f, 1.f};
+    float ld_inv;
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + 256 * i;
-            const int cl = e >> 6, p = e & 63;
+            const int cl = e & 7, p = e >> 3;
             const int pix = p0 + 2 * p;
             const int yo = pix / Wo, xo = pix - yo * Wo;
             dn_ci[i] = cl;
             dn_src[i] = (size_t)(2 * yo) * W + 2 * xo;
             dn_off[i] = (2 * p) * RS_ASTRIDE + cl * 4;
+            dn_s[i] = pix_scale(pix, &ld_inv);                   // the two pixels of a pair share their rows (Wo even)
         }
     }
-    const int up_c4 = tid >> 5, up_q = tid & 31;
-    float ld_inv;
-    const float act_s = pix_scale(p0 + (MODE ? 4 * up_q : 2 * (tid & 63)), &ld_inv);      // the pixels this thread stages share one row (W, Wo even / % 4)
+    const int up_c4 = tid & 7, up_q = tid >> 3;
+    const float act_s = MODE ? pix_scale(p0 + 4 * up_q, &ld_inv) : 1.f;      // up: the four pixels this thread stages share one row (W % 4 == 0)
     const f16x8* wbase = wpk + (size_t)nb * n_stage * RS_BFRAGS;
 
     auto prefetch = [&](int s) {
@@ -140,15 +151,15 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float4 r0 = pre_a[2 * i], r1 = pre_a[2 * i + 1];          // (px0 dx0, px0 dx1, px1 dx0, px1 dx1) for dy = 0 / 1
-                rs_put4(s_hi, s_lo, dn_off[i], r0.x, r0.y, r1.x, r1.y, act_s);
-                rs_put4(s_hi, s_lo, dn_off[i] + RS_ASTRIDE, r0.z, r0.w, r1.z, r1.w, act_s);
+                rs_put4(s_hi, s_lo, dn_off[i], r0.x, r0.y, r1.x, r1.y, dn_s[i]);
+                rs_put4(s_hi, s_lo, dn_off[i] + RS_ASTRIDE, r0.z, r0.w, r1.z, r1.w, dn_s[i]);
             }
         } else {
-            const int off = (4 * up_q) * RS_ASTRIDE + up_c4 * 4;
+            const int off = (4 * up_q) * RS_ASTRIDE + up_c4 * 4;            // pixel 4 up_q is even: pixels + 1 and + 3 carry the odd-pixel shift of 8 f16
             rs_put4(s_hi, s_lo, off + 0 * RS_ASTRIDE, pre_a[0].x, pre_a[1].x, pre_a[2].x, pre_a[3].x, act_s);
-            rs_put4(s_hi, s_lo, off + 1 * RS_ASTRIDE, pre_a[0].y, pre_a[1].y, pre_a[2].y, pre_a[3].y, act_s);
+            rs_put4(s_hi, s_lo, off + 1 * RS_ASTRIDE + 8, pre_a[0].y, pre_a[1].y, pre_a[2].y, pre_a[3].y, act_s);
             rs_put4(s_hi, s_lo, off + 2 * RS_ASTRIDE, pre_a[0].z, pre_a[1].z, pre_a[2].z, pre_a[3].z, act_s);
-            rs_put4(s_hi, s_lo, off + 3 * RS_ASTRIDE, pre_a[0].w, pre_a[1].w, pre_a[2].w, pre_a[3].w, act_s);
+            rs_put4(s_hi, s_lo, off + 3 * RS_ASTRIDE + 8, pre_a[0].w, pre_a[1].w, pre_a[2].w, pre_a[3].w, act_s);
         }
     };
 
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void k_resample2x_f16x3(const float* __rest
         f16x8 ah[RS_MT], al[RS_MT];
 #pragma unroll
         for (int m = 0; m < RS_MT; ++m) {
-            const int off = (wm * 64 + m * 16 + frag_row) * RS_ASTRIDE + frag_k;
+            const int off = (wm * 64 + m * 16 + frag_row) * RS_ASTRIDE + frag_k + (MODE ? (frag_row & 1) * 8 : 0);
             ah[m] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
             al[m] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
         }

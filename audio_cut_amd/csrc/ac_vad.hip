@@ -32,19 +32,20 @@ __global__ __launch_bounds__(256) void k_resample_poly_seg(const float* __restri
                                                            const int64_t* __restrict__ out_len, int n_seg, int up, int down,
                                                            const float* __restrict__ hp, int tpp, int64_t n_pre_remove,
                                                            float* __restrict__ out, int64_t n_work) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;           // index over the concatenation of the segments' outputs
-    if (g >= n_work) return;
-    // out_off is increasing and segment s owns [out_off[s], out_off[s] + out_len[s]): binary search over the starts
-    int lo = 0, hi = n_seg - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (out_off[mid] <= g) lo = mid; else hi = mid - 1;
+    // a wave walks AC_RS_PER_WAVE consecutive indices of the concatenation of the segments' (bucket-padded) outputs
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * AC_RS_PER_WAVE;
+    for (int64_t g = g0; g < g0 + AC_RS_PER_WAVE && g < n_work; ++g) {
+        // out_off is increasing and segment s owns [out_off[s], out_off[s] + out_len[s]): binary search over the starts
+        int lo = 0, hi = n_seg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (out_off[mid] <= g) lo = mid; else hi = mid - 1;
+        }
+        const int64_t m = g - out_off[lo];
+        if (m >= out_len[lo]) continue;                                   // bucket padding: stays zero
+        const float v = ac_polyphase_dot_wave(x + in_off[lo], in_len[lo], hp, up, tpp, (m + n_pre_remove) * (int64_t)down);
+        if ((threadIdx.x & 63) == 0) out[g] = v;
     }
-    const int64_t m = g - out_off[lo];
-    if (m >= out_len[lo]) return;                                         // bucket padding: stays zero
-    const int64_t n = in_len[lo];
-    const float* xs = x + in_off[lo];
-    out[g] = ac_polyphase_dot(xs, n, hp, up, tpp, (m + n_pre_remove) * (int64_t)down);
 }
 
 extern "C" int ac_resample_poly_segments(ac_ctx* ctx, const float* x, const int64_t* in_off, const int64_t* in_len,
@@ -54,8 +55,9 @@ extern "C" int ac_resample_poly_segments(ac_ctx* ctx, const float* x, const int6
     AC_REQUIRE(ctx && x && in_off && in_len && out_off && out_len && h && out, "null pointer");
     AC_REQUIRE(n_seg > 0 && up > 0 && down > 0 && hlen > 0 && n_pre_remove >= 0 && n_out_total > 0, "sizes must be positive");
     AC_REQUIRE(hlen % up == 0 && hlen / up < (1LL << 31), "h is [up][hlen / up] polyphase rows");
-    AC_REQUIRE((n_out_total + 255) / 256 < (1LL << 31), "output too long");
-    hipLaunchKernelGGL(k_resample_poly_seg, dim3((unsigned)((n_out_total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, in_off, in_len,
+    const int64_t blocks = (n_out_total + 4 * AC_RS_PER_WAVE - 1) / (4 * AC_RS_PER_WAVE);
+    AC_REQUIRE(blocks < (1LL << 31), "output too long");
+    hipLaunchKernelGGL(k_resample_poly_seg, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, in_off, in_len,
                        out_off, out_len, n_seg, up, down, h, (int)(hlen / up), n_pre_remove, out, n_out_total);
     AC_LAUNCH_CHECK();
     return AC_OK;

@@ -74,25 +74,7 @@ def conv3x3_wide_tileable(c_out: int, c_in: int) -> bool:
     return c_out % 96 == 0 and c_in % 16 == 0
 
 
-def conv3x3_mixed_tileable(c_out: int, c_in: int) -> bool:
-    """shapes `ac_conv3x3_f16x3_mix` takes: C_out = 96 k + 48 with k >= 1 (the U-Net's C = 144, 240)."""
-    return c_out > 96 and c_out % 96 == 48 and c_in % 16 == 0
-
-
-def pack_conv3x3_mixed(weight: np.ndarray) -> Tuple[np.ndarray, float]:
-    """Weights for `ac_conv3x3_f16x3_mix`: the first 96 k output channels in the 96-channel layout of `pack_conv3x3_w96`, then the last
-    48 in its 48-channel layout, under ONE weight scale.  Result: (flat uint16, w_unscale)."""
-    co = weight.shape[0]
-    if not conv3x3_mixed_tileable(co, weight.shape[1]):
-        raise ValueError("pack_conv3x3_mixed needs C_out = 96 k + 48, k >= 1, C_in % 16 == 0")
-    scale = weight_scale(weight)
-    n_wide = co // 96
-    wide, _ = pack_conv3x3_w96(weight[:96 * n_wide], 96, scale=scale)
-    narrow, _ = pack_conv3x3_w96(weight[96 * n_wide:], 48, scale=scale)
-    return np.concatenate((wide.reshape(-1), narrow.reshape(-1))), 1.0 / scale
-
-
-def pack_conv3x3_w96(weight: np.ndarray, cob: int = 96, scale: float = None) -> Tuple[np.ndarray, float]:
+def pack_conv3x3_w96(weight: np.ndarray, cob: int = 96) -> Tuple[np.ndarray, float]:
     """Weights for `ac_conv3x3_f16x3_w96` (cob = 96) / `ac_conv3x3_f16x3_s8` (cob = 48) (csrc/ac_conv96.hip): K walks stages
     of 8 input channels; a k-step of 32 is 4 taps x 8 channels (lane group g: tap 4 ks + g, ks = 0, 1); the third k-step of a
     stage with cb % 4 == 3 carries tap 8 of the stages cb - 3 + g, and the last stage of a trailing group of two (C_in % 32 == 16)
@@ -101,7 +83,7 @@ def pack_conv3x3_w96(weight: np.ndarray, cob: int = 96, scale: float = None) -> 
     co, ci, kh, kw = weight.shape
     if (kh, kw) != (3, 3) or cob not in (48, 96) or co % cob or ci % 16:
         raise ValueError("pack_conv3x3_w96 needs [C_out % cob == 0, C_in % 16 == 0, 3, 3], cob 96 or 48")
-    scale = weight_scale(weight) if scale is None else scale
+    scale = weight_scale(weight)
     hi, lo = split_hi_lo(np.asarray(weight, dtype=np.float32) * np.float32(scale))
     taps = np.zeros((2, co, ci + 8, 9), dtype=np.uint16)                                                 # channels ci.. = zeros
     taps[0, :, :ci] = hi.view(np.uint16).reshape(co, ci, 9)

@@ -148,7 +148,7 @@ class _Block(nn.Module):
         """Kernel-ready copies of the folded weights: f16 hi/lo MFMA fragments for the 3x3 convs (ac_conv3x3_f16x3_w96 / _s8,
         ac_conv3x3_f16x3_first for the fused first one) and for the wide TDF layers (ac_tdf_linear_f16x3); float32 fragments
         for the narrow TDF pairs of the deep levels (ac_tdf_small_fused)."""
-        from .conv_pack import conv3x3_mixed_tileable, conv3x3_wide_tileable, pack_conv3x3_mixed, pack_conv3x3_w96, pack_linear, pack_tdf_small
+        from .conv_pack import conv3x3_wide_tileable, pack_conv3x3_w96, pack_linear, pack_tdf_small
         w0 = self.lw0.detach().cpu().numpy(); w1 = self.lw1.detach().cpu().numpy()
         dev = self.lw0.device
         self._l_unscale = [None, None]
@@ -172,9 +172,6 @@ class _Block(nn.Module):
             if conv3x3_wide_tileable(w.shape[0], w.shape[1]):
                 wide, unscale = pack_conv3x3_w96(w, 96)
                 self.register_buffer(f"cwq{j}", torch.from_numpy(wide.view(np.int16)).to(dev))
-            elif conv3x3_mixed_tileable(w.shape[0], w.shape[1]):                # C = 144, 240: 96-channel tiles + one 48-channel tile, one launch
-                mixed, unscale = pack_conv3x3_mixed(w)
-                self.register_buffer(f"cwm{j}", torch.from_numpy(mixed.view(np.int16)).to(dev))
             else:
                 narrow, unscale = pack_conv3x3_w96(w, 48)
                 self.register_buffer(f"cws{j}", torch.from_numpy(narrow.view(np.int16)).to(dev))
@@ -183,7 +180,7 @@ class _Block(nn.Module):
     def _conv(self, x: torch.Tensor, ax: torch.Tensor, j: int, hip, tape: _AmaxTape, probe):
         """3x3 conv + bias + ReLU: one fused kernel on the f16 matrix cores (3-term hi/lo split, float32-class accuracy)."""
         from .._native import NativeError
-        if x.shape[2] % 8 or x.shape[3] % 32 or not (hasattr(self, f"cwq{j}") or hasattr(self, f"cwm{j}") or hasattr(self, f"cws{j}")):
+        if x.shape[2] % 8 or x.shape[3] % 32 or not (hasattr(self, f"cwq{j}") or hasattr(self, f"cws{j}")):
             raise NativeError(f"3x3 conv of shape {tuple(x.shape)} is not tileable by the HIP kernels (C % 48, C_in % 16, H % 8, W % 32)")
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -191,9 +188,6 @@ class _Block(nn.Module):
         ay = tape.new(x.shape[2])
         if hasattr(self, f"cwq{j}"):
             y = hip.conv3x3_f16x3_w96(x, getattr(self, f"cwq{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True,
-                                      in_amax=ax, out_amax=ay)
-        elif hasattr(self, f"cwm{j}"):
-            y = hip.conv3x3_f16x3_mix(x, getattr(self, f"cwm{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True,
                                       in_amax=ax, out_amax=ay)
         else:
             y = hip.conv3x3_f16x3_s8(x, getattr(self, f"cws{j}"), getattr(self, f"cb{j}"), x.shape[1], self._w_unscale[j], relu=True,

@@ -495,11 +495,11 @@ def main() -> None:
             for _ in range(3):           # the median of three: a single probe caught allocator / clock hiccups of 2-3x now and then
                 torch.cuda.synchronize()
                 tl = time.perf_counter()
-                lat = splitters[0].split_track(tracks[0], audio_dev=tracks_dev[0])
+                lat = pipeline.run([job_for(tracks[0], tracks_dev[0])])[0]      # the same machinery (worker stream, U-Net stream, allocator pools), one track in flight
                 torch.cuda.synchronize()
                 lat_ms.append((time.perf_counter() - tl) * 1e3)
             out["single_stream_latency_ms"] = round(sorted(lat_ms)[1], 2)
-            out["single_stream_latency_note"] = "one track alone on the GPU (pipeline depth 1, host tail not overlapped), median of " + \
+            out["single_stream_latency_note"] = "one track alone on the GPU (one job through the pipeline: host tail not overlapped), median of " + \
                 str([round(v, 1) for v in lat_ms]) + "; same result: " + str(lat["sample_boundaries"] == step_results[0]["sample_boundaries"])
             out["framewise_rooflines"] = framewise_rooflines(hip, tracks_dev[0])
         if world == 1 and args.cpu_baseline_seconds > 0:

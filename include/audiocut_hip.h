@@ -318,12 +318,7 @@ int ac_conv3x3_f16x3_w96(ac_ctx* ctx, const float* x, const void* w_packed, cons
  * conv_pack.pack_conv3x3_w96(w, cob=48)): the layers ac_conv3x3_f16x3_w96 cannot take. */
 int ac_conv3x3_f16x3_s8(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
                         int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
-/* The same convolution for C_out = 96 k + 48 (k >= 1: the U-Net's levels 2 and 4, C = 144 / 240) in ONE launch: the first k channel
- * blocks of every pixel tile run the 96-channel workgroup tile of ac_conv3x3_f16x3_w96, the last one the 48-channel tile of
- * ac_conv3x3_f16x3_s8 (identical arithmetic and summation order: bit-identical to either).  w_packed = the wide blocks' fragments
- * followed by the narrow block's, one common weight scale (conv_pack.pack_conv3x3_mixed). */
-int ac_conv3x3_f16x3_mix(ac_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* out, int B, int C_in,
-                         int C_out, int H, int W, float w_unscale, int relu, const float* in_amax, float* out_amax, void* stream);
+
 
 /* ---- Silero VAD (vocal_pause_detector.py:175-296 behind silero_chunk_vad.py:56-117) ----------------------- */
 

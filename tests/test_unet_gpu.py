@@ -118,40 +118,6 @@ def test_conv3x3_f16x3_w96_kernel(hip_ctx):
         assert float((y - F.relu(full)).abs().max() / full.abs().max()) < 2e-6
 
 
-def test_conv3x3_mixed_width_kernel_is_bit_identical_to_the_48_channel_one(hip_ctx):
-    """ac_conv3x3_f16x3_mix (C_out = 96 k + 48: 96-channel tiles + one 48-channel tile in one launch; the U-Net's C = 144 and 240)
-    against a float64 convolution and, bit for bit, against ac_conv3x3_f16x3_s8 on the same weights - with and without the
-    time-local activation scale, including a cliff that sends tiles down the row-exact path."""
-    import torch.nn.functional as F
-    from audio_cut_amd.separation.conv_pack import conv3x3_mixed_tileable, pack_conv3x3_mixed, pack_conv3x3_w96, weight_scale
-    g = torch.Generator().manual_seed(11)
-    dev = hip_ctx.device
-    assert conv3x3_mixed_tileable(144, 144) and conv3x3_mixed_tileable(240, 240) and not conv3x3_mixed_tileable(48, 48) \
-        and not conv3x3_mixed_tileable(96, 96) and not conv3x3_mixed_tileable(144, 40)
-    for ci, co, h, w_ in ((144, 144, 64, 768), (240, 240, 16, 192), (48, 144, 16, 64)):
-        x = (torch.randn(2, ci, h, w_, generator=g) * 2)
-        x[1, :, h // 2:] *= torch.logspace(0, -30, h - h // 2).view(1, -1, 1)          # item 1 decays by decades per row: row-exact tiles
-        x = x.to(dev)
-        wt = torch.randn(co, ci, 3, 3, generator=g) / np.sqrt(9 * ci)
-        b = (torch.randn(co, generator=g) * 0.1).to(dev)
-        pm, um = pack_conv3x3_mixed(wt.numpy())
-        ps, us = pack_conv3x3_w96(wt.numpy(), 48)
-        assert um == us == 1.0 / weight_scale(wt.numpy())
-        wm = torch.from_numpy(pm.view(np.int16)).to(dev); ws = torch.from_numpy(ps.view(np.int16)).to(dev)
-        full = F.conv2d(x[:1].double().cpu(), wt.double(), b.double().cpu(), padding=1)
-        ia = _blk_amax(x.cpu()).to(dev)
-        for relu in (True, False):
-            for amax in (None, ia):
-                oa_m = torch.zeros((2, h), device=dev); oa_s = torch.zeros((2, h), device=dev)
-                ym = hip_ctx.conv3x3_f16x3_mix(x, wm, b, co, um, relu=relu, in_amax=amax, out_amax=oa_m)
-                ys = hip_ctx.conv3x3_f16x3_s8(x, ws, b, co, us, relu=relu, in_amax=amax, out_amax=oa_s)
-                assert torch.equal(ym, ys) and torch.equal(oa_m, oa_s), (ci, co, relu, amax is not None)
-                ref = F.relu(full) if relu else full
-                assert float((ym[:1].double().cpu() - ref).abs().max() / full.abs().max()) < 2e-6
-    with pytest.raises(Exception):
-        hip_ctx.conv3x3_f16x3_mix(torch.zeros(1, 96, 8, 32, device=dev), wm, b, 96, 1.0)
-
-
 def test_tdf_linear_f16x3_kernel(hip_ctx):
     """ac_tdf_linear_f16x3 (GEMM + per-channel affine + ReLU (+ residual)) against float64 on the U-Net's TDF shapes."""
     import torch.nn.functional as F

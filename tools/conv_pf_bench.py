@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_cut_amd import _native
 if os.environ.get("AC_LIB"):            # A/B runs: another build of the library (make OUT=../libaudiocut_hip_<tag>.so BUILD=build_<tag> EXTRA=-D...)
     _native._LIB_NAME = os.environ["AC_LIB"]
-from audio_cut_amd.separation.conv_pack import pack_conv3x3_mixed, pack_conv3x3_w96
+from audio_cut_amd.separation.conv_pack import pack_conv3x3_w96
 hip = _native.Context()
 dev = hip.device
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -15,10 +15,9 @@ for c, h, w_ in ((48, 256, 3072), (96, 128, 1536), (144, 64, 768), (192, 32, 384
     x = (torch.randn(B, c, h, w_, generator=g) * 2).to(dev)
     wt = torch.randn(c, c, 3, 3, generator=g) / np.sqrt(9 * c)
     b = (torch.randn(c, generator=g) * 0.1).to(dev)
-    mixed = c % 96 == 48 and c > 48 and not os.environ.get("AC_NO_MIX")        # what the network runs: 96-channel tiles + one 48-channel tile
-    packed, un = pack_conv3x3_mixed(wt.numpy()) if mixed else pack_conv3x3_w96(wt.numpy(), cob)
+    packed, un = pack_conv3x3_w96(wt.numpy(), cob)
     wp = torch.from_numpy(packed.view(np.int16)).to(dev)
-    fn = hip.conv3x3_f16x3_mix if mixed else (hip.conv3x3_f16x3_w96 if cob == 96 else hip.conv3x3_f16x3_s8)
+    fn = hip.conv3x3_f16x3_w96 if cob == 96 else hip.conv3x3_f16x3_s8
     ia = x.abs().amax(dim=(1, 3)).contiguous()
     out = torch.empty_like(x)
     oa = torch.zeros((B, h), device=dev)

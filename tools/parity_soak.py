@@ -14,9 +14,12 @@ from audio_cut_amd.testing import signals
 from audio_cut_amd import config as C
 from oracle import e2e as OE, refine as OR, silero as OS
 import tempfile, os
+sys.path.insert(0, '/root/repo/tests')
+from guard_plateau import boundary_context, classify_boundaries, map_cuts      # the equivalence class of a boundary decided on numerical dust
 OR.LEGACY_PROMOTION = True
 hip = _native.Context()
 ok_all = True
+n_exact = n_equiv = n_fail = 0
 for arg in sys.argv[1:]:
     parts = arg.split(",")
     dur, sseed, wseed = float(parts[0]), int(parts[1]), int(parts[2])
@@ -47,9 +50,19 @@ for arg in sys.argv[1:]:
     ok = (r["sample_boundaries"] == ref.sample_boundaries and r["cuts_samples"] == cuts_ref and
           (flags_ref is None or [bool(f) for f in r["segment_vocal_flags"]] == [bool(f) for f in flags_ref]) and stem < 1e-4 and
           (silero_seed is None or r["vad_segments"] == ref.vad_segments))
-    ok_all &= ok
+    # "exact" and "plateau-equivalent" are counted separately (tests/guard_plateau.py: a boundary may differ from the oracle's only
+    # where the oracle's own dB series are bit-equal at the two indices - the epsilon plateau of digital silence - with the stem
+    # around it within 1e-5 of the peak; never a sample tolerance)
+    verdict = "exact" if ok else "MISMATCH"
+    if not ok and stem < 1e-4 and len(r["sample_boundaries"]) == len(ref.sample_boundaries) and (silero_seed is None or r["vad_segments"] == ref.vad_segments):
+        ctx = boundary_context(ref.vocal, mix, ref.sample_boundaries, 44100)
+        ex, equiv, fails = classify_boundaries(r["sample_boundaries"], ref.sample_boundaries, ctx, r["vocal_track"], stem_atol=1e-5 * peak)
+        if not fails and equiv and map_cuts(r["cuts_samples"], equiv) == list(cuts_ref):
+            verdict = f"plateau-equivalent {equiv}"
+    n_exact += verdict == "exact"; n_equiv += verdict.startswith("plateau"); n_fail += verdict == "MISMATCH"
+    ok_all &= verdict != "MISMATCH"
     print(f"{gen} {dur:g}s song_seed={sseed} weights_seed={wseed}" + (f" silero_seed={silero_seed} vad_segments={len(ref.vad_segments)}" if silero_seed is not None else "") + f": guard boundaries {len(ref.sample_boundaries)} "
-          f"manifest cuts {len(cuts_ref)} pauses {len(ref.pauses)} | exact={ok} stem_err={stem:.2e} rms_series_rel={rms:.2e} | gpu {tg:.2f}s oracle {to:.0f}s", flush=True)
+          f"manifest cuts {len(cuts_ref)} pauses {len(ref.pauses)} | {verdict} | stem_err={stem:.2e} rms_series_rel={rms:.2e} | gpu {tg:.2f}s oracle {to:.0f}s", flush=True)
     if not ok:
         print("  gpu   :", r["sample_boundaries"], r["cuts_samples"]); print("  oracle:", ref.sample_boundaries, cuts_ref)
         # how close was each moved decision?  The guard takes argmin of the 80 ms moving-RMS dB series (refine.py:184-214): compare
@@ -63,4 +76,5 @@ for arg in sys.argv[1:]:
                     print(f"    boundary {o_i} (oracle) vs {g_i} (gpu): oracle vocal dB differs by {abs(dv[g_i - lo] - dv[o_i - lo]):.3e}, "
                           f"mix dB by {abs(dm[g_i - lo] - dm[o_i - lo]):.3e}; vocal level there {dv[o_i - lo]:.6f} dB, |vocal| {abs(float(ref.vocal[o_i])):.2e}, |mix| {abs(float(mix[o_i])):.2e}")
     del backend, sp
-print("ALL EXACT" if ok_all else "MISMATCH")
+print(f"tracks: {n_exact} exact, {n_equiv} plateau-equivalent, {n_fail} mismatched")
+print("ALL EXACT" if (ok_all and not n_equiv) else ("NO MISMATCH" if ok_all else "MISMATCH"))
