@@ -49,12 +49,13 @@ def gather_summaries(local: List[Dict], group=None) -> List[Dict]:
 
 
 class TrackPipeline:
-    """Software pipeline over the tracks of ONE GPU: `depth` worker threads, each with its own HIP stream and its own
-    `SeamlessSplitter` (they share the read-only backend / U-Net weights).  While one track sits in its host-bound tail
-    (VAD bookkeeping, pause detection, guard, boundary policy: ~20 ms of small kernels and synchronisation round trips)
-    the next track's U-Net launches keep the GPU busy from the other stream; `separation_gate` keeps the U-Nets themselves
-    one after the other (two at once would only slow each other down).  Tracks stay independent: no state is shared
-    between workers, results come back in submission order."""
+    """Software pipeline over the tracks of ONE GPU: `depth` worker threads, each with its own high-priority HIP stream and its own
+    `SeamlessSplitter` (they share the read-only backend / U-Net weights), plus ONE U-Net stream for all of them.  A worker queues its
+    track's separation on the U-Net stream under `separation_gate` (held only while queueing), then runs the track's host-bound tail
+    (VAD bookkeeping, pause detection, guard, boundary policy: ~20 ms of small kernels and synchronisation round trips) on its own
+    stream while the next track's U-Net - already waiting in the queue - runs: the GPU never idles between two tracks, and two U-Nets
+    never run at once (that only slows both: the package power is the shared budget).  Tracks stay independent: no state is shared
+    between workers, results come back in submission order and are bit-identical to one-at-a-time processing."""
 
     def __init__(self, splitters: Sequence, device) -> None:
         import threading

@@ -74,10 +74,11 @@ class SeamlessSplitter:
     def split_track(self, original_audio: np.ndarray, mode: str = "v2.2_mdd", *, audio_dev=None, separation_gate=None,
                     unet_stream=None) -> Dict:
         """Steps 2-9 of SURVEY.md §3.1 on an in-memory mono float32 track at `sample_rate`.
-        `separation_gate` (a lock shared by the workers of a `batch.TrackPipeline`): held from this track's first separation
-        kernel until its U-Net has left the GPU, released before the host-bound tail so that the next track overlaps it.  (Queueing the
-        next U-Net behind a GPU-side event instead was measured slower: the tail's ~100 small kernels then wait behind
-        1-2 ms U-Net kernels at every synchronisation round trip.)"""
+        `separation_gate` (a lock shared by the workers of a `batch.TrackPipeline`) and `unet_stream` (the pipeline's one U-Net
+        stream): with both, this track's separation is queued on that stream under the lock and the lock is released as soon as it is
+        queued - the stream itself keeps the U-Nets of consecutive tracks one after the other, and the next one waits in the queue
+        behind the running one.  With the gate alone (round 2's scheme) the lock is held until this track's U-Net has left the GPU and
+        released before the host-bound tail."""
         if mode not in self.SUPPORTED_MODES:
             raise NotImplementedError(f"mode {mode!r}: only the v2.2_mdd / v2.1 path is built this round")
         sr = self.sample_rate

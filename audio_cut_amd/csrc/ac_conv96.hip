@@ -318,13 +318,12 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int tap = 4 * ks + g;
-            const int dy = tap / 3, dx = tap - dy * 3;
+            const int dy = (4 * ks + g) / 3;              // this lane group's tap row (ROWX only)
             f16x8 bh[4], bl[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
-                const int off = ((ty + dy) * W9_RS + tx + dx + 3) * W9_CB;           // patch column c is staged column c + 3
+                const int ty = 2 * wave + (q >> 1);
+                const int off = b_tap[ks] + ((q >> 1) * W9_RS + (q & 1) * 16) * W9_CB;    // one address register per k-step, q in the offset field
                 bh[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
                 bl[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
                 if (ROWX) { const _Float16 f = ac_rowx_frag_factor(s_ex, ty, dy); bh[q] *= (f16x8)f; bl[q] *= (f16x8)f; }
@@ -345,8 +344,8 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         if (g == (cb & 3) && !(W9_PROBE & 0x10)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ty = 2 * wave + (q >> 1), tx = (q & 1) * 16 + px;
-                const int off = ((ty + 2) * W9_RS + tx + 2 + 3) * W9_CB;
+                const int ty = 2 * wave + (q >> 1);
+                const int off = b_lane + ((2 + (q >> 1)) * W9_RS + 2 + (q & 1) * 16) * W9_CB;
                 k8h[q] = *reinterpret_cast<const f16x8*>(&s_hi[off]);
                 k8l[q] = *reinterpret_cast<const f16x8*>(&s_lo[off]);
                 if (ROWX) { const _Float16 f = ac_rowx_frag_factor(s_ex, ty, 2); k8h[q] *= (f16x8)f; k8l[q] *= (f16x8)f; }

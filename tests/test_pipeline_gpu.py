@@ -549,7 +549,7 @@ def test_c3_batch_of_32_tracks_on_one_gpu(hip_ctx, golden_dir):
     from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
     table = json.loads((golden_dir / "c3_n1_sha1.json").read_text())["tracks"]
     seeds = list(range(100, 132))
-    assert sorted(int(k) for k in table) == seeds
+    assert sorted(int(k) for k in table) == [2] + seeds      # + the C2 bench track (seed 2), which bench.py's N = 1 run starts with
     assert batch.assign_tracks([240.0] * 32, 8) == [[r + 8 * k for k in range(4)] for r in range(8)]
     backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=0), ctx=hip_ctx, max_items_per_forward=32)
     backend.load_model()

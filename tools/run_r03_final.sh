@@ -6,8 +6,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-echo "== pytest -m gpu" > $O/r03_final.log
-timeout -k 10 1500 python -m pytest tests -m gpu -x -q >> $O/r03_final.log 2>&1 || { tail -30 $O/r03_final.log; exit 1; }
+echo "== conv per level" > $O/r03_final.log
+timeout -k 10 200 python tools/conv_pf_bench.py 32 >> $O/r03_final.log 2>&1 || exit 1
+echo "== pytest -m gpu" >> $O/r03_final.log
+timeout -k 10 1700 python -m pytest tests -m gpu -q >> $O/r03_final.log 2>&1 || { tail -30 $O/r03_final.log; exit 1; }
 tail -3 $O/r03_final.log
 echo "== python bench.py (driver's default command)" >> $O/r03_final.log
 ( time timeout -k 10 900 python bench.py > $O/r03_bench_default.json ) 2>> $O/r03_final.log || { tail -5 $O/r03_final.log; exit 1; }
