@@ -31,7 +31,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #ifndef W9_PROBE
 #define W9_PROBE 0                   // bit mask of ablations for the probe builds of tools/sharing_probe_*.py (never the product):
 #endif                               // 1 weights first in LDS, 2 no LDS-DMA, 4 no MFMA, 8 no activation staging, 0x10 no shared tap-8 step,
-                                     // 0x20 no epilogue, 0x40 no K loop, 0x80 no activation loads
+                                     // 0x20 no epilogue, 0x40 no K loop, 0x80 no activation loads, 0x100 weights fetched for stage 0 only (timing probe: what the
+                                     // per-stage weight DMA costs, i.e. what LDS-resident weights could win)
 #ifndef W9_PIPE
 #define W9_PIPE 1                    // software-pipelined fragment reads in the K loop (0: the compiler's schedule, kept for A/B runs)
 #endif
@@ -145,6 +146,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         }
     };
     auto prefetch_w = [&](int cb) {
+        if ((W9_PROBE & 0x100) && cb > 0) return;
         const f16x8* wcb = wbase + (size_t)cb * 3 * W9_KFR;
         f16x8* dst = (cb & 1) ? s_w1 : s_w0;
         const bool third = ((cb & 3) == 3) || cb == n_cb - 1;                       // this stage carries the shared tap-8 k-step
