@@ -23,7 +23,8 @@ class NativeError(RuntimeError):
 
 
 def library_path() -> Path:
-    return Path(__file__).resolve().parent / _LIB_NAME
+    # AUDIOCUT_HIP_LIBNAME: another build of the library next to this file (A/B runs of kernel variants: make OUT=../libaudiocut_hip_<tag>.so)
+    return Path(__file__).resolve().parent / os.environ.get("AUDIOCUT_HIP_LIBNAME", _LIB_NAME)
 
 
 def load() -> C.CDLL:

@@ -4,7 +4,7 @@ import os, sys, numpy as np, torch, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_cut_amd import _native
 if os.environ.get("AC_LIB"):            # A/B runs: another build of the library (make OUT=../libaudiocut_hip_<tag>.so BUILD=build_<tag> EXTRA=-D...)
-    _native._LIB_NAME = os.environ["AC_LIB"]
+    os.environ["AUDIOCUT_HIP_LIBNAME"] = os.environ["AC_LIB"]
 from audio_cut_amd.separation.conv_pack import pack_conv3x3_w96
 hip = _native.Context()
 dev = hip.device

@@ -1,0 +1,16 @@
+#!/bin/bash
+# live parity soak against the CPU oracle on tracks / weight seeds no fixture covers (+ one probe: conv without the per-stage weight DMA)
+set -o pipefail
+mkdir -p gpurun_out
+if [ "$1" = "i" ]; then
+  echo "== conv, probe build without the per-stage weight DMA (timing only, outputs are wrong by construction)" > gpurun_out/r03_soak_i.log
+  AC_LIB=libaudiocut_hip_nowdma.so timeout -k 10 200 python tools/conv_pf_bench.py 32 >> gpurun_out/r03_soak_i.log 2>&1
+  echo "== conv, product build" >> gpurun_out/r03_soak_i.log
+  timeout -k 10 200 python tools/conv_pf_bench.py 32 >> gpurun_out/r03_soak_i.log 2>&1
+  echo "== soak I: v2.2_mdd, energy-gate VAD" >> gpurun_out/r03_soak_i.log
+  timeout -k 10 1000 python tools/parity_soak.py "60,401,71,c1_sine_silence" "90,402,72,c1_sine_silence" "120,403,73,c2_song" "75,404,74,vocal_like" "100,405,75,voice_with_rests" "150,406,76,c2_song" "45,407,77,c1_sine_silence" >> gpurun_out/r03_soak_i.log 2>&1
+else
+  echo "== soak J: Silero network as the chunked VAD (soxr-HQ-specification resampler)" > gpurun_out/r03_soak_j.log
+  timeout -k 10 1100 python tools/parity_soak.py "60,411,81,c1_sine_silence,3" "90,412,82,c2_song,4" "75,413,83,vocal_like,5" "120,414,84,voice_with_rests,6" "60,415,85,c2_song,7" "80,416,86,c1_sine_silence,8" >> gpurun_out/r03_soak_j.log 2>&1
+fi
+echo rc=$?

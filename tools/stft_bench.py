@@ -4,7 +4,7 @@ import os, sys, hashlib, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_cut_amd import _native
 if os.environ.get("AC_LIB"):
-    _native._LIB_NAME = os.environ["AC_LIB"]
+    os.environ["AUDIOCUT_HIP_LIBNAME"] = os.environ["AC_LIB"]
 from audio_cut_amd.testing import signals
 hip = _native.Context()
 mix = hip.to_device(signals.c2_song(240.0, seed=2))
