@@ -356,8 +356,19 @@ __global__ __launch_bounds__(256) void k_tempogram(const float* __restrict__ env
         for (int q = 0; q < TG_MAX_WIN / 256; ++q) {
             const int lag = threadIdx.x + 256 * q;
             if (lag < win) {
+                // one dependent float64 chain in index order (bit-identical sums); the LDS reads of eight terms are issued together in
+                // front of it - read, wait, multiply, add per term left the chain latency-bound on LDS (3.2 ms per launch)
                 double a = 0.0;
-                for (int i = 0; i + lag < win; ++i) a += s_y[i] * s_y[i + lag];
+                int i = 0;
+                const int ie = win - lag;
+                for (; i + 8 <= ie; i += 8) {
+                    double u[8], v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { u[k] = s_y[i + k]; v[k] = s_y[i + k + lag]; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a += u[k] * v[k];
+                }
+                for (; i < ie; ++i) a += s_y[i] * s_y[i + lag];
                 s_ac[lag] = a;
                 lmax = fmax(lmax, fabs(a));
             }

@@ -333,8 +333,20 @@ __global__ __launch_bounds__(256) void k_quiet_guard_slow(const float* __restric
         const int w1 = min(seg, w0 + per);
         if (w0 < w1) {
             // windows [w, w+win) for w in [w0, w1): common core [w1-1, w0+win)
+            // the additions stay one dependent float64 chain in index order (bit-identical sums); only the LDS reads are taken eight
+            // at a time in front of it - one read, one wait, one add per iteration left the ~3 500-term chain latency-bound on LDS
+            // (0.2-3.5 ms per launch for a few dozen queries)
             double core = 0.0;
-            for (int i = w1 - 1; i < w0 + win; ++i) core += (double)s_sq[i] * inv;
+            int ci = w1 - 1;
+            const int ce = w0 + win;
+            for (; ci + 8 <= ce; ci += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = s_sq[ci + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) core += (double)t[u] * inv;
+            }
+            for (; ci < ce; ++ci) core += (double)s_sq[ci] * inv;
             double head[QG_RUN_MAX];            // head[j] = sum of sq[w0+j .. w1-2]
             double acc = 0.0;
             for (int j = (w1 - 1 - w0) - 1; j >= 0; --j) { acc += (double)s_sq[w0 + j] * inv; head[j] = acc; }
