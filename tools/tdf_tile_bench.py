@@ -3,6 +3,8 @@ usage: python tools/tdf_tile_bench.py [batch]     (AC_TDF_NARROW=1 in a scratch 
 import os, sys, hashlib, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_cut_amd import _native
+if os.environ.get("AC_LIB"):
+    os.environ["AUDIOCUT_HIP_LIBNAME"] = os.environ["AC_LIB"]
 from audio_cut_amd._native import _ptr, _stream, _check
 from audio_cut_amd.separation.conv_pack import pack_linear
 hip = _native.Context()
