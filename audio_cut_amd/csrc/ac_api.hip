@@ -157,7 +157,7 @@ extern "C" int ac_host_beat_dp(const double* localscore, int64_t n, double perio
     std::vector<double> txwt(wn);
     for (int64_t j = 0; j < wn; ++j) {
         double l = log(-(double)(w0 + j) / period);
-        txwt[j] = -tightness * l * l;
+        txwt[j] = -tightness * (l * l);           // numpy's association (-tightness * log(.) ** 2): (-tightness * l) * l differs by an ulp and breaks ties the other way
     }
     double maxscore = localscore[0];
     for (int64_t i = 1; i < n; ++i) if (localscore[i] > maxscore) maxscore = localscore[i];

@@ -76,6 +76,36 @@ def test_host_beat_dp_matches_oracle_dp(lib):
         np.testing.assert_allclose(cum, cum_o, rtol=1e-12)
 
 
+def test_host_beat_dp_breaks_ties_like_numpy():
+    """Round-3 soak finding (profiles/r03_parity_soak_k.log: c1_sine_silence 120 s, seed 423): on a burst / digital-silence track the
+    beat DP is full of candidates that tie to the last bit (the local score is ~1e-100 for seconds on end), so the transition weights
+    must be numpy's to the ulp: `-tightness * log(.) ** 2` squares first - `(-tightness * l) * l` rounds differently and moved a
+    backlink, a beat (frame 1404 vs 1403) and, through the layout refiner's beat snap, a manifest cut by 1 744 samples.  Bit-for-bit
+    tables, and the beat grid of that track's own onset envelope."""
+    from audio_cut_amd import _native
+    from audio_cut_amd.analysis import rhythm as R
+    from audio_cut_amd.testing import signals
+    from oracle import chunking as C, features as OF, librosa_ops as L
+    sr = 44100
+    mix = signals.c1_sine_silence(120.0, seed=423)
+    plans = C.chunk_plan(len(mix) / float(sr), 10.0, 2.5, 0.5)
+    feat = OF.ChunkFeatureOracle(sr)
+    for plan, (cs, ce, es, ee) in zip(plans, C.plan_sample_ranges(plans, sr, len(mix))):
+        if ce > cs and ee > es:
+            feat.add_chunk(plan, mix[cs:ce], sr)
+    cache = feat.finalize(mix)
+    env = np.asarray(cache.onset_envelope, dtype=np.float32)
+    hop = cache.hop_length
+    bpm = float(L.tempo(env, sr=sr, hop_length=hop)[0])
+    period = round(60.0 * (float(sr) / hop) / bpm)
+    score = L._beat_local_score(env, period)
+    back_o, cum_o = L._beat_track_dp(score, period, 100.0)
+    back, cum = _native.host_beat_dp(score, period, 100.0)
+    assert np.array_equal(back, back_o) and np.array_equal(cum, cum_o)          # every tie the same way, every sum the same bits
+    want = np.round(np.asarray(cache.beat_times) * sr / hop).astype(int)
+    assert want.size == 106 and np.array_equal(R.beat_frames(env, bpm, sr, hop), want)
+
+
 def test_gpu_pipeline_mirror(golden_dir):
     from audio_cut_amd.utils import gpu_pipeline as gp
     assert set(gp.__all__) == {"Streams", "ChunkPlan", "PipelineConfig", "PipelineContext", "PinnedBufferPool", "InflightLimiter",

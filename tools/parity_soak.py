@@ -63,6 +63,11 @@ for arg in sys.argv[1:]:
     ok_all &= verdict != "MISMATCH"
     print(f"{gen} {dur:g}s song_seed={sseed} weights_seed={wseed}" + (f" silero_seed={silero_seed} vad_segments={len(ref.vad_segments)}" if silero_seed is not None else "") + f": guard boundaries {len(ref.sample_boundaries)} "
           f"manifest cuts {len(cuts_ref)} pauses {len(ref.pauses)} | {verdict} | stem_err={stem:.2e} rms_series_rel={rms:.2e} | gpu {tg:.2f}s oracle {to:.0f}s", flush=True)
+    bt_g = np.asarray(r["feature_cache"].beat_times, dtype=np.float64); bt_o = np.asarray(ref.cache.beat_times, dtype=np.float64)
+    beats_equal = bt_g.shape == bt_o.shape and bool(np.array_equal(bt_g, bt_o))
+    if not beats_equal:        # the beat grid feeds the layout refiner's beat snap (a manifest cut can move by up to beat_snap_ms)
+        print(f"  beat_times differ: gpu {bt_g.size} beats, oracle {bt_o.size}; bpm gpu {getattr(getattr(r['feature_cache'], 'bpm_features', None), 'main_bpm', None)} oracle {getattr(getattr(ref.cache, 'bpm_features', None), 'main_bpm', None)}; "
+              f"first difference at {next((i for i in range(min(bt_g.size, bt_o.size)) if bt_g[i] != bt_o[i]), min(bt_g.size, bt_o.size))}: gpu {bt_g[:6]}... oracle {bt_o[:6]}...")
     if not ok:
         print("  gpu   :", r["sample_boundaries"], r["cuts_samples"]); print("  oracle:", ref.sample_boundaries, cuts_ref)
         # how close was each moved decision?  The guard takes argmin of the 80 ms moving-RMS dB series (refine.py:184-214): compare

@@ -9,6 +9,9 @@ if [ "$1" = "i" ]; then
   timeout -k 10 200 python tools/conv_pf_bench.py 32 >> gpurun_out/r03_soak_i.log 2>&1
   echo "== soak I: v2.2_mdd, energy-gate VAD" >> gpurun_out/r03_soak_i.log
   timeout -k 10 1000 python tools/parity_soak.py "60,401,71,c1_sine_silence" "90,402,72,c1_sine_silence" "120,403,73,c2_song" "75,404,74,vocal_like" "100,405,75,voice_with_rests" "150,406,76,c2_song" "45,407,77,c1_sine_silence" >> gpurun_out/r03_soak_i.log 2>&1
+elif [ "$1" = "k" ]; then
+  echo "== soak K: longer tracks; Silero mode on burst / silence tracks (where the burst-calibrated synthetic network does fire)" > gpurun_out/r03_soak_k.log
+  timeout -k 10 1150 python tools/parity_soak.py "240,421,91,c2_song" "120,423,93,c1_sine_silence,10" "150,424,94,c1_sine_silence,11" "200,425,95,voice_with_rests" "180,426,96,vocal_like" >> gpurun_out/r03_soak_k.log 2>&1
 else
   echo "== soak J: Silero network as the chunked VAD (soxr-HQ-specification resampler)" > gpurun_out/r03_soak_j.log
   timeout -k 10 1100 python tools/parity_soak.py "60,411,81,c1_sine_silence,3" "90,412,82,c2_song,4" "75,413,83,vocal_like,5" "120,414,84,voice_with_rests,6" "60,415,85,c2_song,7" "80,416,86,c1_sine_silence,8" >> gpurun_out/r03_soak_j.log 2>&1
