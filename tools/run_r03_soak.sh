@@ -12,6 +12,9 @@ if [ "$1" = "i" ]; then
 elif [ "$1" = "k" ]; then
   echo "== soak K: longer tracks; Silero mode on burst / silence tracks (where the burst-calibrated synthetic network does fire)" > gpurun_out/r03_soak_k.log
   timeout -k 10 1150 python tools/parity_soak.py "240,421,91,c2_song" "120,423,93,c1_sine_silence,10" "150,424,94,c1_sine_silence,11" "200,425,95,voice_with_rests" "180,426,96,vocal_like" >> gpurun_out/r03_soak_k.log 2>&1
+elif [ "$1" = "m" ]; then
+  echo "== soak M: every generator again, half of the tracks with the Silero network" > gpurun_out/r03_soak_m.log
+  timeout -k 10 1150 python tools/parity_soak.py "97,441,111,c2_song" "133,442,112,c2_song,15" "88,443,113,vocal_like,16" "111,444,114,vocal_like" "123,445,115,voice_with_rests,17" "77,446,116,voice_with_rests" "66,447,117,c1_sine_silence,18" "101,448,118,c1_sine_silence" >> gpurun_out/r03_soak_m.log 2>&1
 else
   echo "== soak J: Silero network as the chunked VAD (soxr-HQ-specification resampler)" > gpurun_out/r03_soak_j.log
   timeout -k 10 1100 python tools/parity_soak.py "60,411,81,c1_sine_silence,3" "90,412,82,c2_song,4" "75,413,83,vocal_like,5" "120,414,84,voice_with_rests,6" "60,415,85,c2_song,7" "80,416,86,c1_sine_silence,8" >> gpurun_out/r03_soak_j.log 2>&1
