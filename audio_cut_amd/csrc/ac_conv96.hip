@@ -36,9 +36,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #ifndef W9_PIPE
 #define W9_PIPE 1                    // software-pipelined fragment reads in the K loop (0: the compiler's schedule, kept for A/B runs)
 #endif
-#ifndef W9_STAGEMAP
-#define W9_STAGEMAP 0                // experiment: staging threads walk rows fastest (2-way instead of 4-way store conflicts)
-#endif
 #ifndef W9_S8_OCC
 #define W9_S8_OCC 3                  // workgroups per CU of the 48-channel variant
 #endif
@@ -98,15 +95,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     const float* xb = x + (size_t)b * (FIRST ? C0 : C_in) * plane;
     // staging: thread -> (row 0..9, column quad 0..9, channel quad 0..1): one aligned float4 (4 pixels) of 4 channels each
     const int a_c4 = tid & 1, a_rest = tid >> 1;
-#if W9_STAGEMAP
-    // rows fastest within blocks of four rows: the 8 lane pairs of a ds_write_b64 group then cover 4 rows x 2 quads = 2-way instead of
-    // 4-way bank conflicts (a row is 800 B = 32 B mod 128, a quad 64 B)
-    const int a_blk = a_rest / 40, a_i = a_rest - a_blk * 40;
-    const int a_row = a_blk < 2 ? 4 * a_blk + (a_i & 3) : 8 + (a_i & 1);
-    const int a_qd = a_blk < 2 ? (a_i >> 2) : (a_i >> 1);
-#else
     const int a_row = a_rest / 10, a_qd = a_rest - a_row * 10;
-#endif
     const bool a_live = a_rest < W9_PH * 10;
     // common path: one scale for the tile = the maximum over exactly the patch rows y0 - 1 .. y0 + 8 (ex_min is its log2)
     float act_s = ex_min == AC_EX_NONE ? 1.f : ldexpf(1.f, ex_min);
