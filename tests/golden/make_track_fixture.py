@@ -42,6 +42,7 @@ def main() -> None:
     ap.add_argument("--silero-calib", default="bursts")
     ap.add_argument("--mode", default="v2.2_mdd", choices=["v2.2_mdd", "vpbd_acoustic"])
     ap.add_argument("--name", required=True)
+    ap.add_argument("--light", action="store_true", help="keep the on_plateau flags but not the per-boundary dB / stem windows (100 KB instead of MBs)")
     a = ap.parse_args()
 
     if a.mode == "vpbd_acoustic":           # the reference's VPBD host logic, over the restated librosa ops (make_golden.py)
@@ -109,6 +110,8 @@ def main() -> None:
     n = len(mix)
     plateau = plateau_db()
     ctx = boundary_context(ref.vocal, mix, bounds, sr, HALF)
+    if a.light:
+        ctx = {"on_plateau": ctx["on_plateau"]}
     print(f"boundaries on the epsilon plateau ({plateau:.6f} dB): {[int(b) for b, p in zip(bounds, ctx['on_plateau']) if p]}", flush=True)
 
     sec = sr
