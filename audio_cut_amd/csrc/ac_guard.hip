@@ -409,8 +409,18 @@ __device__ void seg_env_argmin(const float* __restrict__ x, int64_t a, int m, in
         if (o0 >= o1) continue;
         // samples common to every window of the run: j in [o1-1+off-W+1, o0+off]
         const int core_lo = o1 - 1 + off - W + 1, core_hi = o0 + off;
+        // one dependent float64 chain in index order (bit-identical sums); the loads of eight terms are issued together in front of it
         double core = 0.0;
-        for (int j = max(core_lo, 0); j <= min(core_hi, m - 1); ++j) { const float s = x[a + j]; core += (double)(s * s); }
+        int j = max(core_lo, 0);
+        const int je = min(core_hi, m - 1);
+        for (; j + 7 <= je; j += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = x[a + j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) core += (double)(t[u] * t[u]);
+        }
+        for (; j <= je; ++j) { const float s = x[a + j]; core += (double)(s * s); }
         double low[PC_RUN];                         // low[i-o0] = sum over j in [i+off-W+1, core_lo)
         double acc = 0.0;
         for (int i = o1 - 2; i >= o0; --i) {
