@@ -286,6 +286,34 @@ def test_library_has_no_packed_float32_instructions(tmp_path):
     assert n_inst > 1000          # the disassembly really is the kernels (the conv / GEMM MFMA streams are in there)
 
 
+def test_every_lds_dma_sets_m0_right_in_front_of_it(tmp_path):
+    """The 96-channel conv tile issues its weights' LDS-DMA from inline assembly (csrc/ac_conv96.hip `w9_dma16`: hipcc's wait-count pass
+    drains lgkmcnt to 0 at every LDS wait while it knows an LDS-DMA is pending), which writes M0 behind the compiler's back.  That is
+    only sound if nothing relies on an M0 value across such an instruction: in the disassembly of the built library every
+    `global_load_lds` must have its own M0 write close in front of it (measured: 1-8 instructions, the compiler schedules its own a few
+    instructions early; never a value carried from one DMA to the next), and nothing else may read M0 (no s_movrel / ds_gws / sendmsg in
+    these kernels).  The assembly-issued DMA and the compiler's live in different branches of the kernel (PIPE vs the row-exact path)."""
+    import shutil
+    import subprocess
+    from audio_cut_amd import _native
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("no llvm-objdump in this image")
+    lib = tmp_path / "lib.so"
+    shutil.copy(_native.library_path(), lib)
+    subprocess.run([str(objdump), "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    n_dma = 0
+    for part in sorted(tmp_path.glob("lib.so.*gfx950*")):
+        lines = [ln.split("//")[0].strip() for ln in subprocess.run([str(objdump), "-d", str(part)], check=True, capture_output=True, text=True).stdout.splitlines()]
+        lines = [ln for ln in lines if ln and not ln.endswith(":")]
+        for i, ln in enumerate(lines):
+            if "global_load_lds" in ln or ("buffer_load" in ln and " lds" in ln):
+                n_dma += 1
+                assert any("m0" in p for p in lines[max(0, i - 10): i]), f"LDS-DMA without its own M0 write: {lines[max(0, i - 11): i + 1]}"
+            assert not any(op in ln for op in ("s_movrel", "v_movrel", "ds_gws", "s_sendmsg ")), ln
+    assert n_dma > 50          # conv, TDF and resampling kernels all stream their weights by LDS-DMA
+
+
 def test_resampling_filter_meets_the_soxr_hq_specification():
     """the reference resamples with librosa's default soxr_hq (audio_processor.py:44-48, vocal_pause_detector.py:189).
     libsoxr's coefficients cannot be pinned offline; its published HQ specification can: pass band flat to 0.9136 of the lower
