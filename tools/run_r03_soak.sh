@@ -18,6 +18,9 @@ elif [ "$1" = "m" ]; then
 elif [ "$1" = "n" ]; then
   echo "== soak N: final code, eight more tracks" > gpurun_out/r03_soak_n.log
   timeout -k 10 1150 python tools/parity_soak.py "84,451,121,c1_sine_silence,19" "130,452,122,c1_sine_silence" "105,453,123,c2_song" "71,454,124,c2_song,20" "95,455,125,vocal_like" "118,456,126,voice_with_rests" "52,457,127,c1_sine_silence,21" "160,458,128,c2_song" >> gpurun_out/r03_soak_n.log 2>&1
+elif [ "$1" = "o" ]; then
+  echo "== soak O: two long tracks (6 min of the long-form generator, 5 min of the song generator)" > gpurun_out/r03_soak_o.log
+  timeout -k 10 1150 python tools/parity_soak.py "360,461,131,c5_long_form" "300,462,132,c2_song" >> gpurun_out/r03_soak_o.log 2>&1
 else
   echo "== soak J: Silero network as the chunked VAD (soxr-HQ-specification resampler)" > gpurun_out/r03_soak_j.log
   timeout -k 10 1100 python tools/parity_soak.py "60,411,81,c1_sine_silence,3" "90,412,82,c2_song,4" "75,413,83,vocal_like,5" "120,414,84,voice_with_rests,6" "60,415,85,c2_song,7" "80,416,86,c1_sine_silence,8" >> gpurun_out/r03_soak_j.log 2>&1
