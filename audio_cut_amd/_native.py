@@ -142,6 +142,7 @@ class Context:
         with torch.cuda.device(self.index):
             _check(self.lib.ac_ctx_create(self.index, C.byref(handle)))
         self._h = handle
+        self._rs_filters: dict = {}          # (up, down) -> (polyphase rows on the device, n_pre_remove), designed once per context
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -262,7 +263,7 @@ class Context:
 
     def _resample_filter_dev(self, up: int, down: int):
         """(polyphase rows on the device, n_pre_remove) of the (up, down) resampler; designed and uploaded once per context."""
-        cache = self.__dict__.setdefault("_rs_filters", {})
+        cache = self._rs_filters
         if (up, down) not in cache:
             h, n_pre_remove = self._resample_filter(up, down)
             cache[(up, down)] = (self.to_device(self._polyphase_rows(h, up).reshape(-1)), n_pre_remove)
