@@ -23,7 +23,7 @@ class NativeError(RuntimeError):
 
 
 def library_path() -> Path:
-    # AUDIOCUT_HIP_LIBNAME: another build of the library next to this file (A/B runs of kernel variants: make OUT=../libaudiocut_hip_<tag>.so)
+    # AUDIOCUT_HIP_LIBNAME: another build of the library next to this file (A/B runs of kernel variants: make OUT=../libaudiocut_hip_<tag>.so EXTRA=-D...; the objects go to their own build_<hash of EXTRA>/)
     return Path(__file__).resolve().parent / os.environ.get("AUDIOCUT_HIP_LIBNAME", _LIB_NAME)
 
 
