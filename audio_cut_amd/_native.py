@@ -7,9 +7,10 @@ no CPU fallback: a missing library or a failing call raises `NativeError`.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 from pathlib import Path
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -54,6 +55,7 @@ SIGNATURES = {
     "ac_ctx_create": (C.c_int, [_I, C.POINTER(_P)]),
     "ac_ctx_destroy": (C.c_int, [_P]),
     "ac_frame_rms": (C.c_int, [_P, _P, _I64, _I, _I, _I, _P, _I64, _P]),
+    "ac_frame_rms_multi": (C.c_int, [_P, _P, _I64, _I, _P, _P, _P, _P, _P]),
     "ac_stft2048_features": (C.c_int, [_P, _P, _I64, _I, _P, _P, _P, _P, _P, _I64, _P]),
     "ac_onset_strength": (C.c_int, [_P, _P, _I64, _P, _I, _I, _I, _P, _P, _P]),
     "ac_tempogram_parts": (C.c_int, [_I64]),
@@ -143,6 +145,7 @@ class Context:
             _check(self.lib.ac_ctx_create(self.index, C.byref(handle)))
         self._h = handle
         self._rs_filters: dict = {}          # (up, down) -> (polyphase rows on the device, n_pre_remove), designed once per context
+        self._pf = threading.local()         # prefetch cache (one track per worker thread)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -156,11 +159,64 @@ class Context:
             pass
 
     # -- helpers ---------------------------------------------------------------------------------
+    SMALL_UPLOAD_BYTES = 1 << 20
+
     def to_device(self, arr, dtype=None) -> torch.Tensor:
+        """Host array -> device tensor, ordered on the CURRENT stream.  Small arrays (index tables, candidate lists: ~50 per track) go
+        through pinned staging and an asynchronous copy - a pageable upload makes the host wait for the copy each time (20-30 us apiece
+        in the tail of a track); PyTorch's caching host allocator keeps the staging block alive until the copy has run."""
         t = torch.as_tensor(np.ascontiguousarray(arr))
         if dtype is not None:
             t = t.to(dtype)
+        if 0 < t.numel() * t.element_size() <= self.SMALL_UPLOAD_BYTES and not t.is_cuda:
+            staged = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            staged.copy_(t)
+            return staged.to(self.device, non_blocking=True)
         return t.to(self.device, non_blocking=False).contiguous()
+
+    # -- prefetch: kernels whose launch parameters do not depend on host decisions, queued AHEAD of the host logic that consumes them ------
+    # prefetch("frame_rms", x, 2205, 882) runs the wrapper now (on the current stream) and keeps the result; the next frame_rms(x, 2205, 882)
+    # of the SAME thread on the same device memory returns it (after making the current stream wait for the producer) instead of
+    # launching again.  Keys hold the operands' addresses and the entry holds the operands themselves, so the memory cannot be recycled
+    # under a live entry; a parameter the consumer derives differently simply misses (the work is repeated, the result never differs).
+    def prefetch_begin(self) -> None:
+        """Start of a track on this thread: drop whatever an earlier track left unused."""
+        self._pf.entries = {}
+        self._pf.stats = {"queued": 0, "hits": 0}
+
+    def prefetch(self, op: str, *args):
+        ent = getattr(self._pf, "entries", None)
+        if ent is None:
+            self.prefetch_begin(); ent = self._pf.entries
+        self._pf.busy = True
+        try:
+            out = getattr(self, op)(*args)
+        finally:
+            self._pf.busy = False
+        ev = torch.cuda.Event(); ev.record()
+        ent[self._pf_key(op, args)] = (args, out, ev)
+        self._pf.stats["queued"] += 1
+        return out
+
+    @staticmethod
+    def _pf_key(op: str, args) -> tuple:
+        return (op,) + tuple((a.data_ptr(), a.numel()) if isinstance(a, torch.Tensor) else a for a in args)
+
+    def _pf_take(self, op: str, *args):
+        ent = getattr(self._pf, "entries", None)
+        if not ent or getattr(self._pf, "busy", False):
+            return None
+        hit = ent.pop(self._pf_key(op, args), None)
+        if hit is None:
+            return None
+        torch.cuda.current_stream().wait_event(hit[2])
+        self._pf.stats["hits"] += 1
+        return hit[1]
+
+    def prefetch_stats(self) -> dict:
+        st = dict(getattr(self._pf, "stats", {"queued": 0, "hits": 0}))
+        st["unused"] = [k[0] for k in getattr(self._pf, "entries", {})]
+        return st
 
     def _chk_f32(self, x: torch.Tensor) -> None:
         if x.dtype != torch.float32 or x.device != self.device or x.dim() != 1:
@@ -169,6 +225,9 @@ class Context:
     # -- framewise ---------------------------------------------------------------------------------
     def frame_rms(self, x: torch.Tensor, frame: int, hop: int, center: bool = True) -> torch.Tensor:
         self._chk_f32(x)
+        hit = self._pf_take("frame_rms", x, int(frame), int(hop), bool(center))
+        if hit is not None:
+            return hit
         n = x.numel()
         pad = frame // 2 if center else 0
         if n + 2 * pad < frame:
@@ -178,11 +237,41 @@ class Context:
         _check(self.lib.ac_frame_rms(self._h, _ptr(x), n, frame, hop, int(center), _ptr(out), nf, _stream()))
         return out
 
+    def frame_rms_multi(self, x: torch.Tensor, configs: Sequence[Tuple[int, int]]) -> list:
+        """`frame_rms(x, frame, hop, center=True)` for up to four (frame, hop) pairs in ONE pass over x (bit-identical series)."""
+        self._chk_f32(x)
+        n = x.numel()
+        k = len(configs)
+        frames = (C.c_int * k)(*[int(f) for f, _ in configs]); hops = (C.c_int * k)(*[int(h) for _, h in configs])
+        nfs = [1 + (n + 2 * (int(f) // 2) - int(f)) // int(h) for f, h in configs]
+        if min(nfs) < 1:
+            raise NativeError("signal shorter than one frame")
+        outs = [torch.empty(nf, dtype=torch.float32, device=self.device) for nf in nfs]
+        ptrs = (C.c_void_p * k)(*[o.data_ptr() for o in outs]); nfa = (C.c_int64 * k)(*nfs)
+        _check(self.lib.ac_frame_rms_multi(self._h, _ptr(x), n, k, frames, hops, ptrs, nfa, _stream()))
+        return outs
+
+    def prefetch_frame_rms_multi(self, x: torch.Tensor, configs: Sequence[Tuple[int, int]]) -> None:
+        """One fused pass now; each series is then found by the `frame_rms(x, frame, hop)` call that wants it."""
+        ent = getattr(self._pf, "entries", None)
+        if ent is None:
+            self.prefetch_begin(); ent = self._pf.entries
+        outs = self.frame_rms_multi(x, configs)
+        ev = torch.cuda.Event(); ev.record()
+        for (f, h), o in zip(configs, outs):
+            args = (x, int(f), int(h), True)
+            ent[self._pf_key("frame_rms", args)] = (args, o, ev)
+            self._pf.stats["queued"] += 1
+
     def stft2048_features(self, x: torch.Tensor, hop: int, *, want_flat: bool = True, want_mel: bool = False,
                           frame_center: Optional[torch.Tensor] = None, frame_lo: Optional[torch.Tensor] = None,
                           frame_hi: Optional[torch.Tensor] = None):
         self._chk_f32(x)
         n = x.numel()
+        if frame_center is None and want_flat and not want_mel:
+            hit = self._pf_take("stft2048_flatness", x, int(hop))
+            if hit is not None:
+                return hit, None
         nf = frame_center.numel() if frame_center is not None else 1 + n // hop
         flat = torch.empty(nf, dtype=torch.float32, device=self.device) if want_flat else None
         mel = torch.empty((nf, 128), dtype=torch.float32, device=self.device) if want_mel else None
@@ -492,13 +581,23 @@ class Context:
         return cen.cpu().numpy(), rat.cpu().numpy()
 
     # -- guard ---------------------------------------------------------------------------------------
+    def stft2048_flatness(self, x: torch.Tensor, hop: int) -> torch.Tensor:
+        """Spectral flatness per frame of the whole wave (the prefetchable form of stft2048_features(x, hop, want_flat=True))."""
+        return self.stft2048_features(x, hop, want_flat=True, want_mel=False)[0]
+
     def moving_meansq_db(self, x: torch.Tensor, win: int) -> torch.Tensor:
         self._chk_f32(x)
+        hit = self._pf_take("moving_meansq_db", x, int(win))
+        if hit is not None:
+            return hit
         out = torch.empty(x.numel(), dtype=torch.float64, device=self.device)
         _check(self.lib.ac_moving_meansq_db_f64(self._h, _ptr(x), x.numel(), win, _ptr(out), _stream()))
         return out
 
     def next_leq_scan(self, db: torch.Tensor, floor_db: float) -> torch.Tensor:
+        hit = self._pf_take("next_leq_scan", db, float(floor_db))
+        if hit is not None:
+            return hit
         n = db.numel()
         out = torch.empty(n, dtype=torch.int64, device=self.device)
         scratch = torch.empty(int(self.lib.ac_next_leq_scratch(n)), dtype=torch.int64, device=self.device)
@@ -712,15 +811,24 @@ class Context:
                                       float(w_unscale), pi, po, _stream()))
         return out
 
+    def sum_squares_parts(self, x: torch.Tensor) -> torch.Tensor:
+        """Block partial sums of x^2 (float64) on the device; the host adds them in index order (mean_square)."""
+        self._chk_f32(x)
+        hit = self._pf_take("sum_squares_parts", x)
+        if hit is not None:
+            return hit
+        n = x.numel()
+        parts = min(1024, max(1, n // 4096))
+        buf = torch.empty(parts, dtype=torch.float64, device=self.device)
+        _check(self.lib.ac_sum_squares(self._h, _ptr(x), n, _ptr(buf), parts, _stream()))
+        return buf
+
     def mean_square(self, x: torch.Tensor) -> float:
         self._chk_f32(x)
         n = x.numel()
         if n == 0:
             return 0.0
-        parts = min(1024, max(1, n // 4096))
-        buf = torch.empty(parts, dtype=torch.float64, device=self.device)
-        _check(self.lib.ac_sum_squares(self._h, _ptr(x), n, _ptr(buf), parts, _stream()))
-        return float(np.sum(buf.cpu().numpy())) / float(n)
+        return float(np.sum(self.sum_squares_parts(x).cpu().numpy())) / float(n)
 
 
 def host_beat_dp(localscore: np.ndarray, period: float, tightness: float):

@@ -39,7 +39,7 @@ def summarize(track_index: int, sample_boundaries: Sequence[int], seconds: float
 def gather_summaries(local: List[Dict], group=None) -> List[Dict]:
     """Batch completion: barrier + all_gather_object; every rank returns the full, track-ordered list."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return sorted(local, key=lambda d: d["track"])
     dist.barrier(group=group)
     buckets: List[Optional[List[Dict]]] = [None] * dist.get_world_size(group)

@@ -148,6 +148,10 @@ class EnhancedVocalSeparator:
         `separation_gate` (extension, a lock shared by the workers of a `batch.TrackPipeline`): taken right before this
         track's first separation kernel is queued (its index tables are already uploaded) and released once that work
         has left the GPU (the VAD results are back), before the host-bound tail."""
+        if unet_stream is not None and separation_gate is None:
+            # the backend, its network and its scratch are shared by every worker: without the gate two threads interleave one
+            # track's STFT / U-Net / iSTFT launches with another's on that one stream
+            raise ValueError("unet_stream needs separation_gate (batch.TrackPipeline hands out both)")
         backend = self._primary_backend
         if backend is None:
             raise RuntimeError("separator backend not initialised")
@@ -213,14 +217,21 @@ class EnhancedVocalSeparator:
                                      after_launch=drop_gate if unet_stream is not None else None)
         sep_done = torch.cuda.Event()
         sep_done.record()
-
-        # 2. while the U-Net runs: everything that only needs the MIX (`ChunkFeatureBuilder`, BPM / beat analysis) on a
-        #    second, high-priority stream - its small kernels and downloads slot in between the U-Net's launches
-        live_plans = [p for p in plans if min(total, int(round(p.end_s * sr))) > max(0, int(round(p.start_s * sr)))]
+        # the track-global kernels whose parameters no host decision touches (analysis/prefetch.py): the mix's on the side stream
+        # beside the U-Net, the stems' right behind the separation - their consumers (markers, detector, guards) find the results
+        from ..analysis import prefetch as PF
+        hip.prefetch_begin()
         side = self._side_stream(hip)
         with torch.cuda.stream(side):
             side.wait_event(mix_ready)
             mix_dev.record_stream(side)
+            guard_floor = PF.queue_mix_globals(hip, mix_dev, sr)
+        PF.queue_vocal_globals(hip, sep.vocal, sep.instrumental, sr, guard_floor)
+
+        # 2. while the U-Net runs: everything that only needs the MIX (`ChunkFeatureBuilder`, BPM / beat analysis) on a
+        #    second, high-priority stream - its small kernels and downloads slot in between the U-Net's launches
+        live_plans = [p for p in plans if min(total, int(round(p.end_s * sr))) > max(0, int(round(p.start_s * sr)))]
+        with torch.cuda.stream(side):
             feature_builder = ChunkFeatureBuilder(sr=sr, use_gpu=True, device=str(hip.device), ctx=hip)
             feature_builder.attach_track(hip, mix_dev)
             for plan, (cs, ce, es, ee) in zip(live_plans, sep.chunk_ranges):
@@ -238,6 +249,8 @@ class EnhancedVocalSeparator:
             inst_h.copy_(sep.instrumental, non_blocking=True)
             stems_on_host = torch.cuda.Event()
             stems_on_host.record()
+
+        gpu_context.capture_device_metrics()      # an SMI query costs the host ~1 ms: taken here, while it waits for the U-Net anyway (and the GPU is under load)
 
         # 3. chunked VAD on the per-chunk vocals (enhanced_vocal_separator.py:331-333,412-417)
         if self._vad_inference_fn is None:        # Silero network when weights are configured, else the no-weights energy gate
@@ -278,7 +291,6 @@ class EnhancedVocalSeparator:
         gm["gpu_pipeline_chunk_invocations"] = len(sep.chunk_ranges)
         gm["mdx23_output_type"] = backend.get_output_type()
         gm["gpu_pipeline_stage_ms"] = dict(timings)
-        gpu_context.capture_device_metrics()
         state = {"hip": hip, "mix": mix_dev, "vocal": sep.vocal, "instrumental": sep.instrumental, "timings": timings}
         return vocal, inst, cache, vad_segments, markers, confidence, state
 

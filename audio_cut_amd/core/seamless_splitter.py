@@ -538,19 +538,14 @@ class SeamlessSplitter:
         guard_win_ms = float(get_config("quality_control.enforce_quiet_cut.win_ms", 80))
         floor_db = -60.0
         if guard_enabled:
-            override = get_config("quality_control.enforce_quiet_cut.floor_db_override", None)
-            if override is not None:
-                floor_db = float(override)
+            from ..analysis.prefetch import guard_floor_db
+            if get_config("quality_control.enforce_quiet_cut.floor_db_override", None) is not None:
+                floor_db = guard_floor_db(np.zeros(0))
             else:
-                try:
-                    cfg = get_config("quality_control.enforce_quiet_cut.floor_percentile", 5)
-                    pct = float(cfg) / 100.0 if float(cfg) > 1 else float(cfg)
-                except Exception:
-                    pct = 0.05
                 mono = audio_for_split if audio_for_split.ndim == 1 else np.mean(audio_for_split, axis=0)
                 if mono.size > 0:
                     _, rms_db = self._rms2048_db(mono, mix_dev if audio_for_split.ndim == 1 else None)
-                    floor_db = float(np.percentile(rms_db, max(0.0, min(100.0, pct * 100.0))))
+                    floor_db = guard_floor_db(rms_db)
         ctx = CutContext(sr=sr, mix_wave=audio_for_split, vocal_wave=pure_vocal_audio, mix_dev=mix_dev, vocal_dev=vocal_dev,
                          hip=self._context())
         use_vocal_guard = pure_vocal_audio is not None

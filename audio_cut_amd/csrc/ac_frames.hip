@@ -49,6 +49,69 @@ extern "C" int ac_frame_rms(ac_ctx* ctx, const float* x, int64_t n, int frame, i
     return AC_OK;
 }
 
+// Several (frame, hop) configurations of one wave in one pass: a block stages the samples around AC_RMSM_SPAN frame centres once
+// and its waves walk every configuration's frames centred in that range (summation exactly as k_frame_rms: bit-identical series).
+#define AC_RMSM_SPAN 8192
+struct RmsMultiCfg {
+    int n_cfg, reach;                     // reach = samples staged on either side of the block's centre range
+    int frame[AC_RMS_MULTI_MAX], hop[AC_RMS_MULTI_MAX];
+    float* out[AC_RMS_MULTI_MAX];
+    int64_t n_frames[AC_RMS_MULTI_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_frame_rms_multi(const float* __restrict__ x, int64_t n, RmsMultiCfg cfg) {
+    extern __shared__ float s_sq[];
+    const int64_t c0 = (int64_t)blockIdx.x * AC_RMSM_SPAN;            // frame centres [c0, c0 + SPAN) belong to this block
+    const int64_t span0 = c0 - cfg.reach;
+    const int span = AC_RMSM_SPAN + 2 * cfg.reach;
+    for (int i = threadIdx.x; i < span; i += 256) {
+        const int64_t g = span0 + i;
+        s_sq[i] = (g >= 0 && g < n) ? x[g] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c = 0; c < cfg.n_cfg; ++c) {
+        const int frame = cfg.frame[c], hop = cfg.hop[c], pad = frame / 2;
+        const int64_t f_lo = (c0 + hop - 1) / hop;
+        int64_t f_hi = (c0 + AC_RMSM_SPAN + hop - 1) / hop;
+        f_hi = f_hi < cfg.n_frames[c] ? f_hi : cfg.n_frames[c];
+        for (int64_t f = f_lo + w; f < f_hi; f += 4) {
+            const float* p = s_sq + (f * hop - pad - span0);
+            double acc = 0.0;
+            for (int i = lane; i < frame; i += 64) { const double v = (double)p[i]; acc += v * v; }
+            acc = wave_sum_f64(acc);
+            if (lane == 0) cfg.out[c][f] = (float)sqrt(acc / (double)frame);
+        }
+    }
+}
+
+extern "C" int ac_frame_rms_multi(ac_ctx* ctx, const float* x, int64_t n, int n_cfg, const int* frame, const int* hop,
+                                  float* const* out, const int64_t* n_frames, void* stream) {
+    AC_REQUIRE(ctx && x && frame && hop && out && n_frames, "null pointer");
+    AC_REQUIRE(n > 0 && n_cfg >= 1 && n_cfg <= AC_RMS_MULTI_MAX, "1 <= n_cfg <= AC_RMS_MULTI_MAX");
+    RmsMultiCfg cfg;
+    cfg.n_cfg = n_cfg; cfg.reach = 0;
+    int64_t last_centre = 0;
+    for (int c = 0; c < n_cfg; ++c) {
+        AC_REQUIRE(frame[c] > 0 && hop[c] > 0 && out[c] && n_frames[c] > 0, "sizes must be positive");
+        const int pad = frame[c] / 2;
+        AC_REQUIRE(n + 2 * (int64_t)pad >= frame[c] && n_frames[c] == 1 + (n + 2 * (int64_t)pad - frame[c]) / hop[c], "n_frames != 1 + (n + 2*pad - frame)/hop");
+        AC_REQUIRE(frame[c] <= 8192, "frame too large for the LDS span");
+        cfg.frame[c] = frame[c]; cfg.hop[c] = hop[c]; cfg.out[c] = out[c]; cfg.n_frames[c] = n_frames[c];
+        const int reach = pad > frame[c] - pad ? pad : frame[c] - pad;
+        cfg.reach = reach > cfg.reach ? reach : cfg.reach;
+        const int64_t lc = (n_frames[c] - 1) * hop[c];
+        last_centre = lc > last_centre ? lc : last_centre;
+    }
+    for (int c = n_cfg; c < AC_RMS_MULTI_MAX; ++c) { cfg.frame[c] = 1; cfg.hop[c] = 1; cfg.out[c] = nullptr; cfg.n_frames[c] = 0; }
+    const int64_t blocks = last_centre / AC_RMSM_SPAN + 1;
+    AC_REQUIRE(blocks < (1LL << 31), "too many frames");
+    const size_t lds = ((size_t)AC_RMSM_SPAN + 2 * (size_t)cfg.reach) * sizeof(float);
+    hipLaunchKernelGGL(k_frame_rms_multi, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, n, cfg);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
 // =================================================================================================
 // STFT-2048 (float64, like librosa.stft which multiplies the float64 Hann into the frames before
 // the FFT and only then rounds to complex64) -> power -> flatness / mel-128.

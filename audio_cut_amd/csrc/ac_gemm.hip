@@ -17,6 +17,10 @@
 // next stage's global loads are issued before the current stage's MFMAs.  Epilogue: accumulators -> per-wave LDS
 // strip -> affine + ReLU (+ residual) -> 384-byte (192-byte for NT = 3) contiguous row stores.
 #include "ac_common.h"
+#include <stdlib.h>
+#ifndef AC_PROBES
+#define AC_PROBES 0                   // 1: work-order overrides from the environment (tools/tdf_order_probe.py); never in the product build
+#endif
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -34,7 +38,8 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ resid, float* __restrict__ y,
                                                              int n_mblk, int N, int K, int T, int C, float w_unscale,
-                                                             const float* __restrict__ in_amax, float* __restrict__ out_amax) {
+                                                             const float* __restrict__ in_amax, float* __restrict__ out_amax,
+                                                             int ord_g, int ord_r) {
     constexpr int BN = 32 * NT;                       // columns per workgroup
     constexpr int BFRAGS = 2 * (BN / 16) * 64;        // 16-byte weight fragments per stage (hi, lo)
     constexpr int B_ITERS = BFRAGS / 256;             // 6 (NT = 6) or 3
@@ -53,11 +58,16 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n_nblk = N / BN;
-    // XCD-aware work order (see ac_conv.hip): XCD `L & 7` walks a contiguous strip; the column blocks of one row
-    // block are adjacent items, so the x tile crosses the fabric once and the siblings hit L2.
+    // XCD-aware work order (see ac_conv.hip): XCD `L & 7` walks a contiguous strip of the order below, its ~64 resident workgroups
+    // are consecutive in it.  The walk goes over super-groups of ord_r row tiles: inside one, ord_g column blocks of a row tile are
+    // neighbours (they share the x tile in L2), then the next row tile, and only then the next ord_g column blocks - so the
+    // resident workgroups hold ord_g column blocks' weights between them, not all of them (w9_tdf_order picks the two).
     int wi = blockIdx.x;
     if ((gridDim.x & 7) == 0) wi = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int nb = wi % n_nblk, mb = wi / n_nblk;
+    const int per = ord_r * n_nblk;
+    const int chunk = wi / per, i_in = wi - chunk * per;
+    const int nb_hi = i_in / (ord_g * ord_r), j_in = i_in - nb_hi * (ord_g * ord_r);
+    const int nb = nb_hi * ord_g + j_in % ord_g, mb = chunk * ord_r + j_in / ord_g;
     if (mb >= n_mblk) return;
     const int n0 = nb * BN;
     const int n_stage = K / GM_BK;
@@ -77,7 +87,6 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
         s_inv[tid] = inv;
         s_tmax[tid] = 0u;
     }
-    __syncthreads();
 
     f32x4 acc[GM_MT][NT];
 #pragma unroll
@@ -88,14 +97,12 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     // staging coordinates: float4 e covers row e >> 3, k-quad e & 7 (8 lanes = one 128-byte row segment)
     const float* a_ptr[GM_A_ITERS];
     int a_off[GM_A_ITERS];
-    float a_scale[GM_A_ITERS];
 #pragma unroll
     for (int i = 0; i < GM_A_ITERS; ++i) {
         const int e = tid + 256 * i;
         const int row = e >> 3, kq = e & 7;
         a_ptr[i] = x + grow(row) * (size_t)K + 4 * kq;
         a_off[i] = row * GM_ASTRIDE + 4 * kq;
-        a_scale[i] = s_scale[row & 7];
     }
     const f16x8* wbase = wpk + (size_t)nb * n_stage * BFRAGS;
 
@@ -110,9 +117,13 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
 #pragma unroll
         for (int i = 0; i < GM_A_ITERS; ++i) pre_a[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)s * GM_BK);
     };
+    prefetch(0);                         // stage 0 is on its way while the eight scales (a dependent global load) arrive
+    __syncthreads();
+    float a_scale[GM_A_ITERS];
+#pragma unroll
+    for (int i = 0; i < GM_A_ITERS; ++i) a_scale[i] = s_scale[((tid + 256 * i) >> 3) & 7];
 
     const int frag_row = lane & 15, frag_k = 8 * (lane >> 4);
-    prefetch(0);
     for (int s = 0; s < n_stage; ++s) {
         __syncthreads();                 // previous stage fully consumed
         const f16x8* s_b = (s & 1) ? s_b1 : s_b0;
@@ -229,18 +240,27 @@ extern "C" int ac_tdf_linear_f16x3(ac_ctx* ctx, const float* x, const void* w_pa
     AC_REQUIRE(N > 0 && N % 96 == 0, "N % 96 == 0");
     const bool wide = (N % 192) == 0;
     const long long n_mblk = M / GM_BM;
-    long long nblk = n_mblk * (N / (wide ? 192 : 96));
+    const int n_nblk = N / (wide ? 192 : 96);
+    long long nblk = n_mblk * n_nblk;
     AC_REQUIRE(nblk < (1LL << 31) - 8 && n_mblk < (1LL << 31), "grid too large");
+    // Work order: 4 column blocks x 16 row tiles per super-group where the shape has them.  With all (8 - 16) column blocks of a row
+    // tile side by side an XCD's 64 resident workgroups stream every column block's weights at once (4.7 MB at level 0: more than its
+    // 4 MB L2) and the layer read 2.32x its algorithmic bytes; 4 x 16 reads 1.66x (profiles/r04c: 12.6 -> 9.0 GB, 3.77 -> 3.70 ms).
+    int ord_g = n_nblk, ord_r = 1;
+    if (n_nblk % 4 == 0 && n_nblk > 4 && n_mblk % 16 == 0) { ord_g = 4; ord_r = 16; }
+#if AC_PROBES
+    if (const char* e = getenv("AC_PROBE_TDF_ORDER")) {                       // "G,R" (tools/tdf_order_probe.py)
+        int g_ = 0, r_ = 0;
+        if (sscanf(e, "%d,%d", &g_, &r_) == 2 && g_ > 0 && r_ > 0 && n_nblk % g_ == 0 && n_mblk % r_ == 0) { ord_g = g_; ord_r = r_; }
+    }
+#endif
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
     const f16x8* wp = (const f16x8*)w_packed;
-    if (wide) {
-        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<6, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
-        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<6, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
-    } else {
-        if (resid) hipLaunchKernelGGL((k_tdf_linear_f16x3<3, true>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
-        else       hipLaunchKernelGGL((k_tdf_linear_f16x3<3, false>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax);
-    }
+#define GM_GO(NT_, RES_) hipLaunchKernelGGL((k_tdf_linear_f16x3<NT_, RES_>), grid, block, 0, st, x, wp, scale, shift, resid, y, (int)n_mblk, N, K, T, C, w_unscale, in_amax, out_amax, ord_g, ord_r)
+    if (wide) { if (resid) GM_GO(6, true); else GM_GO(6, false); }
+    else      { if (resid) GM_GO(3, true); else GM_GO(3, false); }
+#undef GM_GO
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import logging
 import math
+import threading
 import os
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence
@@ -125,7 +126,7 @@ class SileroHipVad:
         self.weights = validate_silero_weights(weights)
         self._ctx = ctx
         self._packed: Optional[dict] = None
-        self.adaptive_params: Optional[Dict[str, float]] = None      # see set_adaptive_params
+        self._adaptive = threading.local()                           # see set_adaptive_params: per THREAD, the object is shared by the workers of a TrackPipeline
         g = math.gcd(SR16, self.sample_rate)
         self._up, self._down = SR16 // g, self.sample_rate // g
 
@@ -133,14 +134,25 @@ class SileroHipVad:
                             speech_pad_ms: Optional[float] = None) -> None:
         """The reference's adaptive branch (`vocal_pause_detector.py:198-206`): when `current_adaptive_params` is set,
         `get_speech_timestamps` runs with its `vad_threshold`, `min_pause_duration` (seconds -> min silence) and `speech_pad_ms`
-        instead of the static configuration.  Call with no arguments to go back to the static parameters."""
+        instead of the static configuration.  Call with no arguments to go back to the static parameters.
+        The parameters belong to a TRACK: one `SileroHipVad` (packed weights on the device) serves every worker thread of a
+        `batch.TrackPipeline`, so what is set here is seen by the calling thread only; `__call__(chunk, adaptive=...)` passes them
+        for one call."""
+        self._adaptive.params = self.adaptive_dict(vad_threshold, min_pause_duration, speech_pad_ms)
+
+    @staticmethod
+    def adaptive_dict(vad_threshold: Optional[float] = None, min_pause_duration: Optional[float] = None,
+                      speech_pad_ms: Optional[float] = None) -> Optional[Dict[str, float]]:
         if vad_threshold is None and min_pause_duration is None and speech_pad_ms is None:
-            self.adaptive_params = None
-            return
+            return None
         if vad_threshold is None or min_pause_duration is None or speech_pad_ms is None:
             raise ValueError("adaptive VAD parameters come as a set: vad_threshold, min_pause_duration, speech_pad_ms")
-        self.adaptive_params = {"threshold": float(vad_threshold), "min_silence_ms": float(int(float(min_pause_duration) * 1000)),
-                                "pad_ms": float(int(speech_pad_ms))}
+        return {"threshold": float(vad_threshold), "min_silence_ms": float(int(float(min_pause_duration) * 1000)),
+                "pad_ms": float(int(speech_pad_ms))}
+
+    @property
+    def adaptive_params(self) -> Optional[Dict[str, float]]:
+        return getattr(self._adaptive, "params", None)
 
     # -- weights in kernel order ------------------------------------------------------------------------
     def _pack(self) -> dict:
@@ -184,7 +196,8 @@ class SileroHipVad:
         return [PrecomputedProbs(probs[f: f + c], n, m, pb) for f, c, n, m, pb in zip(seg_first, counts, lengths, n16, padded_bucket)]
 
     # -- VadFn ---------------------------------------------------------------------------------------------
-    def __call__(self, chunk) -> List[Dict[str, int]]:
+    def __call__(self, chunk, adaptive: Optional[Dict[str, float]] = None) -> List[Dict[str, int]]:
+        """`adaptive`: an `adaptive_dict(...)` for this call only (else the calling thread's `set_adaptive_params`, else static)."""
         import torch
         if not isinstance(chunk, PrecomputedProbs):
             ctx = self._ctx = self._ctx or _native.Context()
@@ -192,7 +205,7 @@ class SileroHipVad:
             if x.numel() == 0:
                 return []
             chunk = self.precompute(x, [0], [int(x.numel())])[0]
-        ap = self.adaptive_params
+        ap = adaptive if adaptive is not None else self.adaptive_params
         stamps = speech_timestamps(
             chunk.probs, chunk.n16_padded, WINDOW, SR16,
             threshold=ap["threshold"] if ap else float(get_config("advanced_vad.silero_prob_threshold_down", 0.35)),

@@ -219,6 +219,8 @@ def framewise_rooflines(hip, mix_dev, reps: int = 8) -> list:
     for frame, hop in ((4410, 2205), (2048, 441), (2205, 882), (1102, 441)):
         nf = 1 + n // hop
         add(f"ac_frame_rms({frame},{hop})", lambda f=frame, h=hop: hip.frame_rms(nxt(), f, h), 4 * n + 4 * nf)
+    add("ac_frame_rms_multi(2205/882 + 1102/441 + 2048/441: the vocal stem's three series in one pass)",
+        lambda: hip.frame_rms_multi(nxt(), [(2205, 882), (1102, 441), (2048, 441)]), 4 * n + 4 * (2 * (1 + n // 441) + 1 + n // 882))
     add("ac_stft2048_features(hop 441, flatness)", lambda: hip.stft2048_features(nxt(), 441, want_flat=True, want_mel=False),
         4 * n + 4 * (1 + n // 441))
     add("ac_stft2048_features(hop 512, mel-128)", lambda: hip.stft2048_features(nxt(), 512, want_flat=False, want_mel=True),
@@ -234,6 +236,33 @@ def framewise_rooflines(hip, mix_dev, reps: int = 8) -> list:
         return hip.next_leq_scan(dbs[k[0]], -40.0)
     add("ac_next_leq_scan", scan, 16 * n)
     return rows
+
+
+def framewise_accounting(n: int) -> dict:
+    """SURVEY.md 8(d) asks for the fused-pass count: how many times a track's full-length waves cross HBM for the framewise / scan
+    kernels, by construction of the product path (analysis/prefetch.py, analysis/features_cache.py, analysis/rhythm.py,
+    cutting/refine.py), beside the reference's count for the same series.  n = samples per track."""
+    w = 4 * n                                                     # one float32 wave
+    rows = [
+        # (wave, kernel, series it yields, float32 wave reads, other bytes, what the reference does)
+        ("vocal", "ac_frame_rms_multi", "RMS 2205/882 (markers) + 1102/441 (detector) + 2048/441 (no-vocal runs)", 1, 0, "3 passes (+ a 4th, 2048/441 for the VPP multiplier, which is dead code and not computed here)"),
+        ("vocal", "ac_stft2048_features hop 441", "spectral flatness (detector)", 1, 0, "1 pass"),
+        ("vocal", "ac_moving_meansq_db_f64 + ac_next_leq_scan", "quiet-guard lookup (dB series f64 + next-quiet i64)", 1, 32 * n, "1 pass + an O(N * 3528) convolution + a 2N-step Python loop"),
+        ("vocal, instrumental", "ac_sum_squares x2", "separation confidence", 2, 0, "2 passes"),
+        ("mix", "ac_sum_squares", "separation confidence", 1, 0, "1 pass"),
+        ("mix", "ac_frame_rms 2048/441", "guard floor percentile", 1, 0, "1 pass"),
+        ("mix", "ac_moving_meansq_db_f64 + ac_next_leq_scan", "quiet-guard lookup", 1, 32 * n, "as for the vocal stem"),
+        ("mix", "ac_segment_frame_rms 4410/2205 (all chunks, one launch)", "cache RMS", 1, 0, "1 pass (per chunk)"),
+        ("mix", "ac_stft2048_features hop 2205 (all chunks, one launch)", "cache flatness + mel-128 onset", 1, 0, "2 passes (flatness, onset_strength)"),
+        ("mix", "ac_stft2048_features hop 512, mel-128", "BPM onset envelope (median) + tempogram", 1, 0, "2 passes (mean and median onset envelopes)"),
+    ]
+    reads = sum(r[3] for r in rows)
+    return {"framewise_fused_passes": reads, "framewise_passes_reference": 15,
+            "framewise_fused_note": "full-length float32 wave reads per track by the framewise / scan kernels (the reference path: 6 RMS + 2 STFT-2048 + "
+                                    "2 mel-onset + 2 guard + 3 mean-square passes = 15); the three RMS series of the vocal stem are ONE pass (ac_frame_rms_multi), "
+                                    "all of them are queued ahead of the host logic that consumes them (analysis/prefetch.py)",
+            "framewise_hbm_bytes_per_track": int(reads * w + sum(r[4] for r in rows)),
+            "framewise_passes": [{"wave": r[0], "kernel": r[1], "yields": r[2], "wave_reads": r[3], "other_bytes": int(r[4]), "reference": r[5]} for r in rows]}
 
 
 C3_SEED0 = 100                         # SURVEY.md 8d: C3 = 32 x C2 with seeds 100-131
@@ -290,7 +319,10 @@ def main() -> None:
     # the gloo backend, so the N > 1 control flow (barriers, MAX over ranks, summary gather) can be exercised without N GPUs.
     rehearsal = os.environ.get("AC_BENCH_REHEARSAL", "") == "1"
     dev_index = 0 if rehearsal else local_rank
-    if world > 1:
+    # AC_BENCH_FORCE_DIST=1 (tests/test_distributed_gpu.py): take the distributed branch with ONE rank too, so that RCCL's
+    # initialisation, a barrier, the MAX all-reduce, all_gather_object over a device and the shutdown run on a one-GPU box
+    use_dist = world > 1 or os.environ.get("AC_BENCH_FORCE_DIST", "") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # N processes share the host: keep each rank's CPU-side torch / OpenMP pools to its share of the cores
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
@@ -340,13 +372,12 @@ def main() -> None:
     vad_fn = None
     if args.config == "c4":
         # BASELINE configs[3]: SileroChunkVAD focus windows.  The real Silero weights cannot be fetched offline: seeded synthetic
-        # weights of the v5 architecture (tests/silero_synth.py), output layer calibrated once with the CPU oracle - the two
-        # calibration numbers travel in the committed fixture, so nothing under oracle/ is imported here
-        sys.path.insert(0, str(ROOT / "tests"))
-        from silero_synth import synth_silero_weights
+        # weights of the v5 architecture (audio_cut_amd/testing/silero_synth.py), output layer calibrated once with the CPU oracle - the
+        # two calibration numbers travel in the committed fixture, so nothing under oracle/ or tests/ is imported here
+        from audio_cut_amd.testing.silero_synth import synth_silero_weights
         from audio_cut_amd.detectors.silero_vad import SileroHipVad
         fx = np.load(c4_fixture)
-        vad_fn = SileroHipVad(sr, synth_silero_weights(int(fx["silero_seed"]), str(fx["silero_calib"]), affine=fx["silero_affine"]), hip)
+        vad_fn = SileroHipVad(sr, synth_silero_weights(int(fx["silero_seed"]), affine=fx["silero_affine"]), hip)
     splitters = [SeamlessSplitter(sr, separator=EnhancedVocalSeparator(sr, backend=backend, vad_inference_fn=vad_fn)) for _ in range(depth)]
     pipeline = batch.TrackPipeline(splitters, device)
     gate = pipeline.separation_gate if (depth > 1 and not args.no_separation_gate) else None
@@ -366,7 +397,7 @@ def main() -> None:
         pipeline.run([job_for(warm[k % len(warm)], warm_dev[k % len(warm)]) for k in range(n_warm)])   # every worker (stream, allocator pools) warms up
         del warm, warm_dev
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     backend.net.conv_probe = []        # HIP events around every 3x3 conv launch of the timed region (same stream)
@@ -392,10 +423,10 @@ def main() -> None:
         sm["seed"] = seeds[mine[step]]; sm["rank"] = rank
         sm["cuts_sha1"] = batch.summarize(0, res.get("cuts_samples", []), 0.0)["boundaries_sha1"]
         summaries.append(sm)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -458,6 +489,8 @@ def main() -> None:
             "value_is": "WHOLE-JOB aggregate over n_gpus (all ranks' audio seconds / max-over-ranks wall time), as the bench contract "
                         "prescribes; divide by n_gpus for the per-GPU figure the metric's name refers to",
             "value_per_gpu": round(total_audio / elapsed / world, 3), "parity_ok": bool(parity_ok),
+            "batch_completion": ({"backend": dist.get_backend(), "collectives": "barrier, all_reduce(MAX), all_gather_object",
+                                  "summaries_gathered": len(all_summaries)} if use_dist else None),
             "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
@@ -502,11 +535,12 @@ def main() -> None:
             out["single_stream_latency_note"] = "one track alone on the GPU (one job through the pipeline: host tail not overlapped), median of " + \
                 str([round(v, 1) for v in lat_ms]) + "; same result: " + str(lat["sample_boundaries"] == step_results[0]["sample_boundaries"])
             out["framewise_rooflines"] = framewise_rooflines(hip, tracks_dev[0])
+            out.update(framewise_accounting(int(tracks_dev[0].numel())))
         if world == 1 and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds, weights, spec)
         out["socket_under_load"] = socket_state
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     # a throughput figure on top of boundaries that differ from the committed single-GPU / CPU-oracle results is not a result:
     # fail the run.  That includes the one-GPU rehearsal of the N > 1 control flow (AC_BENCH_REHEARSAL=1, ranks sharing one device):

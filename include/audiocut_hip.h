@@ -50,6 +50,15 @@ int ac_ctx_destroy(ac_ctx* ctx);
 int ac_frame_rms(ac_ctx* ctx, const float* x, int64_t n, int frame, int hop, int center,
                  float* out, int64_t n_frames, void* stream);
 
+/* The same for up to AC_RMS_MULTI_MAX (frame, hop) configurations of ONE wave in one pass over it (center = True): the three series
+ * the reference takes of the vocal stem after separation - core/vocal_separator.py:483 (2205/882), core/pure_vocal_pause_detector.py:1113
+ * (1102/441), core/seamless_splitter.py:1714 (2048/441) - read the 42 MB stem once instead of three times.  Every frame is summed in
+ * ac_frame_rms's order, so out[c] is bit-identical to ac_frame_rms(x, n, frame[c], hop[c], 1, ...).  frame / hop / out / n_frames are
+ * HOST arrays of n_cfg entries (out[c]: device pointer to n_frames[c] floats). */
+#define AC_RMS_MULTI_MAX 4
+int ac_frame_rms_multi(ac_ctx* ctx, const float* x, int64_t n, int n_cfg, const int* frame, const int* hop,
+                       float* const* out, const int64_t* n_frames, void* stream);
+
 /* STFT(n_fft=2048, periodic Hann, center, zero pad) -> |X|^2 -> spectral flatness and/or mel-128
  * power, one pass.  Replaces librosa.feature.spectral_flatness (features_cache.py:183,
  * pure_vocal_pause_detector.py:1117) and the melspectrogram inside librosa.onset.onset_strength

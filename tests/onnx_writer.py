@@ -42,7 +42,10 @@ def _node(op: str, inputs, outputs, ints=None) -> bytes:
     return msg
 
 
-def write_tfc_tdf_onnx(path, w, spec, *, fold_conv_bn: bool = False, raw: bool = True, gemm_for_tdf: bool = False) -> None:
+def write_tfc_tdf_onnx(path, w, spec, *, fold_conv_bn: bool = False, raw: bool = True, gemm_for_tdf: bool = False,
+                       shuffle_seed=None) -> None:
+    """`shuffle_seed`: write the initializers in a seeded random order (a reader must find them through the nodes' input names, not
+    through their position in the file)."""
     nodes, inits = [], []
     counter = [0]
     cur = ["input"]
@@ -105,6 +108,9 @@ def write_tfc_tdf_onnx(path, w, spec, *, fold_conv_bn: bool = False, raw: bool =
         block(f"dec.{i}")
     emit("Transpose", [], {"perm": [0, 1, 3, 2]})
     conv("final_conv", None)
+    if shuffle_seed is not None:
+        order = np.random.default_rng(shuffle_seed).permutation(len(inits))
+        inits = [inits[i] for i in order]
     graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"tfc_tdf") + b"".join(_ld(5, t) for t in inits)
     model = _vi((1 << 3) | 0) + _vi(8) + _ld(2, b"audio-cut-test-writer") + _ld(7, graph)
     with open(path, "wb") as fh:

@@ -57,6 +57,15 @@ def test_product_fails_loudly_without_gpu():
         PureVocalPauseDetector(SR).detect_pure_vocal_pauses(np.zeros(SR, np.float32))
 
 
+def test_shared_unet_stream_needs_the_gate():
+    """One U-Net stream for every worker is only safe together with the lock that keeps two tracks' launches from interleaving."""
+    from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
+    sep = object.__new__(EnhancedVocalSeparator)
+    sep._primary_backend = None
+    with pytest.raises(ValueError, match="separation_gate"):
+        sep.separate_for_detection(np.zeros(SR, np.float32), unet_stream=object())
+
+
 def test_product_never_imports_the_oracle():
     for path in (ROOT / "audio_cut_amd").rglob("*.py"):
         text = path.read_text()

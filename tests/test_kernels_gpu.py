@@ -35,6 +35,30 @@ def test_frame_rms(hip_ctx, song, gated, frame, hop):
         assert np.array_equal(got == 0.0, ref == 0.0)      # exact-zero frames stay exact zeros
 
 
+def test_frame_rms_multi_is_the_single_kernel_bit_for_bit(hip_ctx, song, gated):
+    """ac_frame_rms_multi: the stem's three RMS series (markers 2205/882, detector 1102/441, no-vocal runs 2048/441) in one pass over
+    the wave - every frame summed in ac_frame_rms's order, so the series are the SAME bits; ragged lengths (a frame centre exactly on
+    the last sample, a wave shorter than one span) included."""
+    cfgs = [(2205, 882), (1102, 441), (2048, 441), (4410, 2205)]
+    rng = np.random.default_rng(5)
+    for x in (song, gated, song[: 8192 * 3 + 1], song[: 441 * 70], rng.standard_normal(5000).astype(np.float32)):
+        xd = hip_ctx.to_device(x)
+        for k in (1, 3, 4):
+            got = hip_ctx.frame_rms_multi(xd, cfgs[:k])
+            for (frame, hop), g in zip(cfgs[:k], got):
+                want = hip_ctx.frame_rms(xd, frame, hop)
+                assert g.shape == want.shape and torch.equal(g, want), (len(x), frame, hop)
+    # the prefetch form: one launch, each series handed to the frame_rms call that asks for it
+    xd = hip_ctx.to_device(song)
+    hip_ctx.prefetch_begin()
+    hip_ctx.prefetch_frame_rms_multi(xd, cfgs[:3])
+    a = hip_ctx.frame_rms(xd, 1102, 441)
+    st = hip_ctx.prefetch_stats()
+    assert st["queued"] == 3 and st["hits"] == 1 and len(st["unused"]) == 2
+    hip_ctx.prefetch_begin()
+    assert torch.equal(a, hip_ctx.frame_rms(xd, 1102, 441)) and hip_ctx.prefetch_stats()["hits"] == 0
+
+
 @pytest.mark.parametrize("hop", [441, 2205, 512])
 def test_stft_flatness_and_mel(hip_ctx, song, hop):
     flat, mel = hip_ctx.stft2048_features(hip_ctx.to_device(song), hop, want_flat=True, want_mel=True)

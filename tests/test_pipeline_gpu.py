@@ -166,6 +166,11 @@ def test_full_path_separate_detect_against_oracle(hip_ctx):
     backend.load_model()
     sp = SeamlessSplitter(SR, separator=EnhancedVocalSeparator(SR, backend=backend))
     res = sp.split_track(mix)
+    # analysis/prefetch.py queues the track-global kernels ahead of their consumers: every one of them must have been picked up (a
+    # parameter derived differently on the two sides would silently repeat the work), and nothing else may sit in the cache
+    st = hip_ctx.prefetch_stats()
+    print("prefetch:", st)
+    assert st["queued"] >= 10 and st["hits"] == st["queued"] and st["unused"] == [], st
     OR.LEGACY_PROMOTION = True
     ref = OE.run_track(mix, SR, w)
     sep = sp.separator.separate_for_detection(mix)
@@ -600,8 +605,9 @@ def test_build_feature_cache_whole_track_variant(hip_ctx):
         build_feature_cache(np.zeros(0, np.float32), None, SR, ctx=hip_ctx)
 
 
-def _run_with_silero(hip_ctx, tmp_path, mix, weight_seed, silero_seed, calib, mode="v2.2_mdd"):
-    """The product path with the Silero network as the chunked VAD (synthetic weights file configured)."""
+def _run_with_silero(hip_ctx, tmp_path, mix, weight_seed, silero_seed, calib, mode="v2.2_mdd", affine=None):
+    """The product path with the Silero network as the chunked VAD (synthetic weights file configured).  `affine`: the output
+    layer's calibration as a fixture stores it (no oracle call)."""
     from audio_cut_amd import config as C
     from audio_cut_amd.core.enhanced_vocal_separator import EnhancedVocalSeparator
     from audio_cut_amd.core.seamless_splitter import SeamlessSplitter
@@ -609,7 +615,7 @@ def _run_with_silero(hip_ctx, tmp_path, mix, weight_seed, silero_seed, calib, mo
     from audio_cut_amd.separation.backends import MDX23HipBackend
     from audio_cut_amd.separation.tfc_tdf import TfcTdfSpec, synth_weights
     from silero_synth import synth_silero_weights
-    np.savez(tmp_path / "silero.npz", **synth_silero_weights(silero_seed, calib=calib))
+    np.savez(tmp_path / "silero.npz", **synth_silero_weights(silero_seed, calib=calib, affine=affine))
     backend = MDX23HipBackend(weights=synth_weights(TfcTdfSpec(), seed=weight_seed), ctx=hip_ctx, max_items_per_forward=32)
     backend.load_model()
     saved = C.snapshot()
@@ -648,6 +654,30 @@ def test_soak_track_on_the_epsilon_plateau_is_exact_or_plateau_equivalent(hip_ct
     assert len(equiv) <= 2, equiv            # round 2 measured one (3 samples); a second one would be news worth reading, not a pass
     assert map_cuts(res["cuts_samples"], equiv) == g["cuts"].tolist()
     assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
+    assert stem_err < 5e-6
+
+
+def test_soak_track_that_exposed_the_beat_dp_tie_is_exact(hip_ctx, golden_dir, tmp_path):
+    """The one live-soak track (round 3, 40 tracks) that exposed a HOST-side defect: c1_sine_silence 120 s, song seed 423, U-Net weights 93,
+    Silero weights 10.  Every guard boundary was exact and ONE manifest cut was 1 744 samples off (3 455 696 vs 3 457 440): the layout
+    refiner's beat snap, fed by a beat grid that left the oracle's at beat 62 - `ac_host_beat_dp` associated its transition weight as
+    (-tightness * l) * l where numpy squares first, one ulp, the other way round at a tie of ~1e-100 local scores
+    (`profiles/r03_parity_soak_m.log`; the DP alone: tests/test_abi_and_host.py::test_host_beat_dp_breaks_ties_like_numpy).  The track
+    itself is the fixture here: beats, boundaries, manifest cuts, labels, VAD segments and pause cut points equal."""
+    g = np.load(golden_dir / "c1_120s_seed423_w93_silero10_oracle.npz")
+    assert float(g["seconds"]) == 120.0 and int(g["seed"]) == 423 and int(g["weight_seed"]) == 93 and int(g["silero_seed"]) == 10
+    mix = signals.c1_sine_silence(120.0, seed=423)
+    res = _run_with_silero(hip_ctx, tmp_path, mix, weight_seed=93, silero_seed=10, calib=str(g["silero_calib"]), affine=g["silero_affine"])
+    bt = np.asarray(res["feature_cache"].beat_times, dtype=np.float64)
+    assert bt.shape == g["beat_times"].shape and np.array_equal(bt, g["beat_times"]), int(np.argmax(bt[: len(g["beat_times"])] != g["beat_times"][: len(bt)]))
+    assert len(bt) > 62                                       # the grid really runs past the beat at which the two once parted
+    assert np.array_equal(np.asarray([[s["start"], s["end"]] for s in res["vad_segments"]], dtype=np.float64).reshape(-1, 2), g["vad_segments"])
+    assert np.array_equal(np.asarray([p.cut_point for p in res["pauses"]]), g["pause_cut_points"])
+    assert res["sample_boundaries"] == g["sample_boundaries"].tolist()
+    assert res["cuts_samples"] == g["cuts"].tolist()
+    assert [int(f) for f in res["segment_vocal_flags"]] == g["flags"].tolist()
+    stem_err = float(np.max(np.abs(res["vocal_track"][: 4 * SR: 7] - g["vocal_head"]))) / float(g["vocal_peak"])
+    print(f"seed 423 / w93 / silero 10: {len(bt)} beats, {len(res['sample_boundaries'])} boundaries, {len(res['cuts_samples'])} manifest cuts exact; stem error {stem_err:.2e}")
     assert stem_err < 5e-6
 
 

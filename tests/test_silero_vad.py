@@ -99,8 +99,14 @@ def test_silero_network_and_timestamps_against_oracle(hip_ctx):
         want = OS.detect_speech_timestamps(c, SR, w, adaptive=(0.5, 0.3, 60))
         assert vad(p) == want
         assert want != OS.detect_speech_timestamps(c, SR, w) or not want
+    # ... seen by the calling thread only (one SileroHipVad serves every worker of a TrackPipeline), or passed for one call
+    import threading
+    seen = []
+    th = threading.Thread(target=lambda: seen.append(vad(pre[0]))); th.start(); th.join()
+    assert seen[0] == OS.detect_speech_timestamps(chunks[0], SR, w)
     vad.set_adaptive_params()
     assert vad(pre[0]) == OS.detect_speech_timestamps(chunks[0], SR, w)
+    assert vad(pre[1], adaptive=vad.adaptive_dict(0.5, 0.3, 60)) == OS.detect_speech_timestamps(chunks[1], SR, w, adaptive=(0.5, 0.3, 60))
 
 
 @pytest.mark.gpu

@@ -375,3 +375,34 @@ def test_tdf_small_fused_kernel(hip_ctx):
     with pytest.raises(Exception):
         hip_ctx.tdf_small_fused(torch.zeros(1, 3, 5, 96, device=dev), torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev), 12,
                                 s1.to(dev), b1.to(dev), s2.to(dev), b2.to(dev))           # rows % 32 != 0: refused
+
+
+def test_product_forward_through_the_onnx_reader(hip_ctx, tmp_path):
+    """SURVEY 8(f) row 3 as far as it can go offline: the full-size network written as an ONNX file the way an exporter writes it
+    (anonymous `onnx::w_N` initializer names, a mix of raw_data / float_data payloads, initializers in shuffled order, MatMul TDFs)
+    and loaded the way the reference's deployment loads `Kim_Vocal_1.onnx` - `MDX23HipBackend(model_dir=...)`, `backends.py:222-255`
+    -> `separation/onnx_weights.py` - must drive the HIP kernels to the SAME bits as the dict-weights network, and to float32-class
+    accuracy against the float64 evaluation."""
+    from pathlib import Path
+    from tests.onnx_writer import write_tfc_tdf_onnx
+    from audio_cut_amd.separation.backends import MDX23HipBackend
+    spec = TfcTdfSpec()
+    w = synth_weights(spec, seed=3)
+    rng = np.random.default_rng(7)
+    for k in list(w):                                       # informative biases / running means (synthetic ones are zeros)
+        if k.endswith("running_mean") or (k.endswith(".bias") and "bn" not in k):
+            w[k] = (rng.standard_normal(w[k].shape) * 0.05).astype(np.float32)
+    model_dir = Path(tmp_path)
+    write_tfc_tdf_onnx(model_dir / "Kim_Vocal_1.onnx", w, spec, fold_conv_bn=False, raw=False, shuffle_seed=11)
+    assert (model_dir / "Kim_Vocal_1.onnx").stat().st_size > 60e6            # the real file is 66.8 MB
+    via_file = MDX23HipBackend(model_dir=model_dir, ctx=hip_ctx); via_file.load_model()
+    via_dict = MDX23HipBackend(weights=w, ctx=hip_ctx); via_dict.load_model()
+    mix = signals.c2_song(10.0, seed=5)
+    batch, _, _ = OC.mdx_windows(mix)
+    x = mdx_stft(batch[:1]).contiguous().to(hip_ctx.device)
+    y_file = via_file.net(x); y_dict = via_dict.net(x)
+    assert torch.equal(y_file, y_dict)                      # same bits: the reader hands the kernels exactly the writer's tensors
+    y64 = unet_torch.forward(via_dict.net, x.double().cpu())
+    err = float((y_file.double().cpu() - y64).abs().max() / y64.abs().max())
+    print(f"forward through the ONNX reader vs float64: {err:.2e}")
+    assert err < 1e-5

@@ -4,6 +4,8 @@ per-dispatch rows tools/pmc_by_dispatch.py maps back to the variants (the sequen
 usage: python tools/conv_order_probe.py [batch]"""
 import os, sys, json, hashlib, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("AC_LIB"):            # the probe build: make OUT=../libaudiocut_hip_probe.so EXTRA=-DAC_PROBES=1
+    os.environ["AUDIOCUT_HIP_LIBNAME"] = os.environ["AC_LIB"]
 from audio_cut_amd import _native
 from audio_cut_amd.separation.conv_pack import pack_conv3x3_w96
 hip = _native.Context(); dev = hip.device

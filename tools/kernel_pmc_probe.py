@@ -1,5 +1,5 @@
 """The U-Net's big kernels, three launches each at the shapes that carry the time (B = 32): the target of rocprofv3 --pmc passes
-(tools/run_pmc_probe.sh) that ask where their waves spend their cycles."""
+(tools/run_gpu_batch.sh <tag> sq_probe) that ask where their waves spend their cycles."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_cut_amd import _native
