@@ -39,7 +39,7 @@ def load() -> C.CDLL:
                           f"(there is no CPU fallback for the HIP path)")
     lib = C.CDLL(str(path))
     _declare(lib)
-    if lib.ac_abi_version() != 4:
+    if lib.ac_abi_version() != 5:
         raise NativeError("libaudiocut_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -179,6 +179,18 @@ __device__ inline void ac_amax_commit_blocks(float m, int blk, float* __restrict
     }
 }
 
+// One 1 KB piece global -> LDS (16 B per lane, lane i lands at lds + 16 i), issued from inline assembly ON PURPOSE: with the
+// builtin the compiler knows an LDS-DMA is in flight and then drains lgkmcnt to 0 in front of every use of a ds_read result for as
+// long as it is pending (measured on the ISA: every fragment wait in the K loop was lgkmcnt(0)); hidden from it, its counted
+// lgkmcnt(N) waits are exact again and fragment reads can stay in flight behind the MFMAs.  The wave's own s_waitcnt vmcnt(0)
+// in front of the stage barrier is what orders the data (as before); M0 is not used by anything else in these kernels.
+// (Shared by the conv kernels' weight stream and the TDF epilogue's residual prefetch.)
+__device__ __forceinline__ void ac_lds_dma16(const void* g, void* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory", "m0");
+}
+
+
 // ---- rational-rate polyphase FIR (ac_resample_poly, ac_resample_poly_segments) ----------------------------------------------------
 // y[m] = sum_q hfull[i - q * up] x[q], i = (m + n_pre_remove) * down, over the n samples of x only (zero extension).  The taps
 // arrive as polyphase ROWS hp[p][t] = hfull[p + t * up] (p < up, t < tpp; rows zero-padded): output m uses row p = i % up against

@@ -53,15 +53,8 @@ template <int GX> struct W9Geo {
 #define W9_FIRST_OCC 3               // workgroups per CU of the fused first conv
 #endif
 
-// One 1 KB piece global -> LDS (16 B per lane, lane i lands at lds + 16 i), issued from inline assembly ON PURPOSE: with the
-// builtin the compiler knows an LDS-DMA is in flight and then drains lgkmcnt to 0 in front of every use of a ds_read result for as
-// long as it is pending (measured on the ISA: every fragment wait in the K loop was lgkmcnt(0)); hidden from it, its counted
-// lgkmcnt(N) waits are exact again and fragment reads can stay in flight behind the MFMAs.  The wave's own s_waitcnt vmcnt(0)
-// in front of the stage barrier is what orders the data (as before); M0 is not used by anything else in these kernels.
-__device__ __forceinline__ void w9_dma16(const void* g, void* lds_wave_base) {
-    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory", "m0");
-}
+// w9_dma16 = ac_lds_dma16 (ac_common.h): the LDS-DMA issued from inline assembly, hidden from the compiler's wait-count pass.
+#define w9_dma16 ac_lds_dma16
 
 __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
@@ -244,6 +237,10 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         }
     };
 
+    // Stage 0's loads and weight DMA are issued HERE, behind the scale prologue.  Issuing them at the very top of the kernel (in flight while
+    // the ten row maxima arrive) was built and measured in round 4: bit-identical and 14 % SLOWER at C = 48 (3.62 -> 4.14 ms), 2 % at C = 96
+    // (profiles/r04i): vmcnt returns in order, so the wait for the (L2-resident) maxima then also waits for the HBM-bound patch loads,
+    // and the three workgroups of a CU stop overlapping their prologues with one another's K loops.
     prefetch_w(0); prefetch_x(0);
     for (int cb = 0; cb < ((W9_PROBE & 0x40) ? 0 : n_cb); ++cb) {
         __syncthreads();                 // previous stage fully consumed

@@ -18,6 +18,9 @@
 // strip -> affine + ReLU (+ residual) -> 384-byte (192-byte for NT = 3) contiguous row stores.
 #include "ac_common.h"
 #include <stdlib.h>
+#ifndef GM_RESID_AHEAD
+#define GM_RESID_AHEAD 0            // 1: all four residual strips of the epilogue requested at once (registers + hidden LDS-DMA): built and measured in round 4, bit-identical and 2 % SLOWER on the same box (profiles/r04j: 3.68 -> 3.75 ms at level 0) - the epilogue is not load-latency-bound; kept switchable
+#endif
 #ifndef AC_PROBES
 #define AC_PROBES 0                   // 1: work-order overrides from the environment (tools/tdf_order_probe.py); never in the product build
 #endif
@@ -47,7 +50,10 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
     constexpr int A_BYTES = 2 * GM_BM * GM_ASTRIDE * 2;
     constexpr int O_BYTES = 4 * 16 * OSTRIDE * 4;
     // the weight fragments are double-buffered and filled by LDS-DMA one stage ahead (they are stored in LDS order already)
-    constexpr int ARENA = (A_BYTES + 2 * BFRAGS * 16) > O_BYTES ? (A_BYTES + 2 * BFRAGS * 16) : O_BYTES;
+    // epilogue: the residual rows of strips 2 and 3 are brought in by LDS-DMA behind the four output strips (R_BYTES per wave)
+    constexpr int R_BYTES = (RESID && GM_RESID_AHEAD) ? 2 * (16 * (16 * NT) * 4) : 0;
+    constexpr int K_ARENA = A_BYTES + 2 * BFRAGS * 16, E_ARENA = O_BYTES + 4 * R_BYTES;
+    constexpr int ARENA = K_ARENA > E_ARENA ? K_ARENA : E_ARENA;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[ARENA];
     unsigned short* s_hi = reinterpret_cast<unsigned short*>(s_raw);
     unsigned short* s_lo = s_hi + GM_BM * GM_ASTRIDE;
@@ -178,6 +184,62 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
         c = cg * 16 + (tr >> 3);
         return grow(tr) * (size_t)N + n0 + wn * (16 * NT) + 4 * q4;
     };
+#if GM_RESID_AHEAD
+    // The residual of ALL four strips is requested at once (until round 4 it was fetched strip by strip, one ahead: the epilogue paid the
+    // load latency about four times per workgroup, with both co-resident workgroups' matrix pipes idle meanwhile): strips 2 and 3 into
+    // registers in front of the barrier, strips 0 and 1 by LDS-DMA into the freed stage buffers right behind it (hidden from the
+    // compiler - ac_lds_dma16 - so that its waits for the register loads are not turned into waits on every LDS access; the explicit
+    // s_waitcnt in front of strip 0 orders the DMA, and nothing younger - no store - is outstanding at that point, so it waits for
+    // exactly these loads).  Lane e of a strip owns float4 e of the strip in every form.
+    static_assert(GM_MT == 4, "the residual prefetch is laid out for four strips");
+    unsigned char* s_res = s_raw + O_BYTES + wave * R_BYTES;
+    if (RESID) {
+#pragma unroll
+        for (int m = 2; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < E_ITERS; ++i) { int c; rr[m - 2][i] = *reinterpret_cast<const float4*>(resid + out_offset(m, i, c)); }
+    }
+    __syncthreads();                     // every wave is done reading the stage buffers
+    if (RESID) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < E_ITERS; ++i) { int c; ac_lds_dma16(resid + out_offset(m, i, c), s_res + (m * E_ITERS + i) * 1024); }
+    }
+    // tile row & 7 = time row of the tile; 16 m and 64 wm are multiples of 8, so float4 i of this lane meets the SAME time row in
+    // every strip: its maximum is carried in a register across the strips and committed once
+    float vm[E_ITERS];
+#pragma unroll
+    for (int i = 0; i < E_ITERS; ++i) vm[i] = 0.f;
+#pragma unroll
+    for (int m = 0; m < GM_MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[(g * 4 + r) * OSTRIDE + n * 16 + px] = acc[m][n][r];
+        if (RESID && m == 0) __builtin_amdgcn_s_waitcnt(0);          // the DMA'd strips have landed (this wave's own pieces only: no barrier needed)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < E_ITERS; ++i) {
+            const int e = lane + 64 * i;
+            const int row = e / ROW_F4, q4 = e - row * ROW_F4;
+            int c;
+            const size_t o = out_offset(m, i, c);
+            const int tr = wm * 64 + m * 16 + row;
+            const float sc = scale[c] * (w_unscale * s_inv[tr & 7]), sh = shift[c];
+            float4 v = *reinterpret_cast<const float4*>(&so[row * OSTRIDE + 4 * q4]);
+            v.x = fmaxf(v.x * sc + sh, 0.f); v.y = fmaxf(v.y * sc + sh, 0.f);
+            v.z = fmaxf(v.z * sc + sh, 0.f); v.w = fmaxf(v.w * sc + sh, 0.f);
+            if (RESID) {
+                const float4 q = m >= 2 ? rr[m - 2][i] : *reinterpret_cast<const float4*>(s_res + (m * E_ITERS + i) * 1024 + lane * 16);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            vm[i] = fmaxf(fmaxf(vm[i], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            *reinterpret_cast<float4*>(y + o) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#else        // round 3's epilogue: the residual fetched strip by strip, one ahead (kept for same-box A/B runs: EXTRA=-DGM_RESID_AHEAD=0)
     if (RESID) {
 #pragma unroll
         for (int i = 0; i < E_ITERS; ++i) { int c; rr[0][i] = *reinterpret_cast<const float4*>(resid + out_offset(0, i, c)); }
@@ -216,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_tdf_linear_f16x3(const float* __rest
         }
         __builtin_amdgcn_wave_barrier();
     }
+#endif
     if (out_amax) {                      // max |y| per time row of the tile
         // a row is ROW_F4 = 24 or 12 float4 long: aligned groups of four lanes always share a row -> two shuffles, then one LDS
         // atomic per group (16 lanes per instruction instead of 64, E_ITERS instructions instead of 4 E_ITERS)

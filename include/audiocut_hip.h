@@ -29,7 +29,7 @@ extern "C" {
 #define AC_E_HIP (-2)       /* a HIP runtime call failed */
 #define AC_E_NOMEM (-3)
 
-#define AC_ABI_VERSION 4
+#define AC_ABI_VERSION 5        /* 5: + ac_frame_rms_multi */
 
 typedef struct ac_ctx ac_ctx;
 

@@ -35,6 +35,21 @@ def main():
     print(f"gaps >= {min_gap / 1e3:.0f} us: {len(big)}, {sum(g[0] for g in big) / 1e6:.2f} ms;  gaps below: {len(gaps) - len(big)}, {sum(g[0] for g in gaps if g[0] < min_gap) / 1e6:.2f} ms")
     for g in sorted(big, key=lambda g: -g[0])[:top]:
         print(f"  {g[0] / 1e3:9.1f} us at +{g[1] / 1e6:10.2f} ms   after {g[2][:60]:60s} before {g[3][:60]}")
+    # context of the largest gaps that lie between two U-Net forwards (a bubble in the pipelined bench): the kernels on either side
+    if len(sys.argv) > 4:
+        ctx = int(sys.argv[4])
+        extra = [c_ for c_ in ("queue_id", "stream_id") if c_ in cols]
+        rows2 = c.execute(f"select start, end, {name}" + "".join(", " + e for e in extra) + " from kernels order by start").fetchall()
+        starts = [r[0] for r in rows2]
+        import bisect
+        unet_k = ("k_conv3x3", "k_tdf", "k_resample2x", "k_conv1x1")
+        inner = [g for g in sorted(big, key=lambda g: -g[0]) if 0.2 * span < g[1] < 0.98 * span][:3]
+        for g in inner:
+            t_gap_end = t0 + g[1] + g[0]
+            i = bisect.bisect_left(starts, t_gap_end)
+            print(f"--- gap of {g[0] / 1e3:.1f} us ending at +{(g[1] + g[0]) / 1e6:.2f} ms; columns {extra}")
+            for r in rows2[max(0, i - ctx):i + ctx]:
+                print(f"   +{(r[0] - t0) / 1e6:10.3f} ms  run {(r[1] - r[0]) / 1e3:8.1f} us  {r[3:]}  {r[2][:70]}")
     # idle inside U-Net forwards vs between them: a gap whose both neighbours are U-Net kernels counts as "inside"
     unet = ("k_conv3x3", "k_tdf", "k_resample2x", "k_conv1x1")
     inside = sum(g[0] for g in gaps if any(u in g[2] for u in unet) and any(u in g[3] for u in unet))

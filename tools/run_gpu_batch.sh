@@ -84,7 +84,7 @@ PY
       ( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/tr -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0 > $O/${TAG}_bench_under_rocprof.json 2>> $L ) || exit 1
       DB=$(find $O/tr -name "*.db" | head -1)
       python3 tools/kernel_stats_from_db.py $DB $O/${TAG}_bench_kernel_stats.csv >> $L 2>&1
-      python3 tools/kernel_gaps.py $DB 20 12 > $O/${TAG}_bench_kernel_gaps.txt 2>&1
+      python3 tools/kernel_gaps.py $DB 20 12 14 > $O/${TAG}_bench_kernel_gaps.txt 2>&1
       rm -rf $O/tr ;;
     tail_trace)
       rm -rf $O/tr
