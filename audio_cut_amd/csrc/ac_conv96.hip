@@ -46,6 +46,9 @@ template <int GX> struct W9Geo {
 #ifndef W9_PIPE
 #define W9_PIPE 1                    // software-pipelined fragment reads in the K loop (0: the compiler's schedule, kept for A/B runs)
 #endif
+#ifndef W9_ASM_DMA_ALL
+#define W9_ASM_DMA_ALL 0             // 1: the hidden (inline assembly) weight DMA in the 48-channel / row-exact variants too (A/B switch)
+#endif
 #ifndef W9_S8_OCC
 #define W9_S8_OCC 3                  // workgroups per CU of the 48-channel variant
 #endif
@@ -174,8 +177,12 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
             if (inst < n_inst) dst[inst * 64 + lane] = wcb[inst * 64 + lane];
 #else
             if (inst < n_inst) {
+#if W9_ASM_DMA_ALL
+                w9_dma16(wcb + inst * 64 + lane, dst + inst * 64);
+#else
                 if constexpr (PIPE) w9_dma16(wcb + inst * 64 + lane, dst + inst * 64);
                 else __builtin_amdgcn_global_load_lds(wcb + inst * 64 + lane, dst + inst * 64, 16, 0, 0);
+#endif
             }
 #endif
         }
