@@ -5,6 +5,7 @@
 # Steps:
 #   conv_levels[:lib]   tools/conv_pf_bench.py 32 (optionally on another build of the library, AC_LIB=libaudiocut_hip_<lib>.so)
 #   conv_order | conv_tile   tools/conv_order_probe.py: time per band width (conv_tile: per tile width of the 48-channel tile) and level, then FETCH_SIZE / WRITE_SIZE per variant
+#   conv_ablation:<tags>  tools/conv_ablation.py on the product and on each libaudiocut_hip_<tag>.so (comma-separated W9_PROBE builds)
 #   tdf_order           tools/tdf_order_probe.py on the probe build: time, FETCH_SIZE / WRITE_SIZE per (column blocks, row tiles) super-group
 #   calib               tools/probes/build/fetch_calib under the raw TCC request counters (FETCH_SIZE / WRITE_SIZE calibration)
 #   tdf_levels[:lib]    tools/tdf_tile_bench.py 32
@@ -34,6 +35,7 @@ for STEP in "$@"; do
   echo "== $STEP" >> $L
   case $NAME in
     conv_levels) AC_LIB=$(libenv $ARG) timeout -k 10 200 python tools/conv_pf_bench.py 32 >> $L 2>&1 || exit 1 ;;
+    conv_ablation) for T in "" ${ARG//,/ }; do AC_LIB=$(libenv $T) timeout -k 10 120 python tools/conv_ablation.py 32 >> $L 2>&1 || exit 1; done ;;
     tdf_levels)  AC_LIB=$(libenv $ARG) timeout -k 10 200 python tools/tdf_tile_bench.py 32 >> $L 2>&1 || exit 1 ;;
     conv_order|conv_tile)
       export AC_PROBE_SET=${NAME#conv_} AC_LIB=libaudiocut_hip_probe.so
