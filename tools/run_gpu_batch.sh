@@ -70,7 +70,7 @@ print("dispatch order:", [names[k] for k in sorted(names)])
 PY
       done
       cat $O/pmc_tmp.log >> $L; rm -rf $O/pmc_tmp ;;
-    unet_tests) AUDIOCUT_HIP_LIBNAME=$(libenv $ARG) timeout -k 10 700 python -m pytest tests/test_unet_gpu.py -m gpu -x -q >> $L 2>&1 || { tail -30 $L; exit 1; } ;;
+    unet_tests) [ -n "$ARG" ] && export AUDIOCUT_HIP_LIBNAME=$(libenv $ARG); timeout -k 10 700 python -m pytest tests/test_unet_gpu.py -m gpu -x -q >> $L 2>&1 || { tail -30 $L; exit 1; } ;;
     gpu_tests)  timeout -k 10 1100 python -m pytest tests -m gpu -q --durations=15 >> $L 2>&1 || { tail -40 $L; exit 1; }; tail -3 $L ;;
     bench)
       timeout -k 10 600 python bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0 ${ARG//,/ } > $O/${TAG}_bench.json 2>> $L || { tail -5 $L; exit 1; }
