@@ -49,6 +49,9 @@ template <int GX> struct W9Geo {
 #ifndef W9_ASM_DMA_ALL
 #define W9_ASM_DMA_ALL 0             // 1: the hidden (inline assembly) weight DMA in the 48-channel / row-exact variants too (A/B switch)
 #endif
+#ifndef W9_PF
+#define W9_PF 1                      // activation-patch prefetch depth of the 48-channel tile in stages.  1: the product.  2 (A/B switch): two register sets and
+#endif                               // LDS-only barriers; 226 VGPRs = two workgroups per CU (-DW9_S8_OCC=2); measured 10 % SLOWER than depth 1 there (profiles/r04x)
 #ifndef W9_S8_OCC
 #define W9_S8_OCC 3                  // workgroups per CU of the 48-channel variant
 #endif
@@ -59,6 +62,19 @@ template <int GX> struct W9Geo {
 // w9_dma16 = ac_lds_dma16 (ac_common.h): the LDS-DMA issued from inline assembly, hidden from the compiler's wait-count pass.
 #define w9_dma16 ac_lds_dma16
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release / acquire fence over ALL address spaces: the compiler puts
+// s_waitcnt vmcnt(0) in front of every s_barrier, so no global load can stay in flight across a stage boundary - a patch prefetch TWO
+// stages ahead (W9_PF 2) would be forced to land one stage early (round 2's depth-2 experiment, profiles/r02g, ran into exactly that).  With
+// this barrier the loads do stay in flight - and the kernel is slower still (profiles/r04x): it is not waiting for its loads.  Global data the
+// kernel reads (patch loads, weight DMA) is waited for by counted s_waitcnt vmcnt where it is consumed; what it writes it never reads.
+__device__ __forceinline__ void w9_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): vector memory operations return in
+// order, so this waits for everything issued before the N youngest
+template <int N> __device__ __forceinline__ void w9_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
 __device__ inline unsigned short w9_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
 #if W9_PROBE & 4                      // probe build: the operands stay live, the matrix instruction is not issued
@@ -75,13 +91,14 @@ __device__ __forceinline__ f32x4 w9_mfma(f16x8 a, f16x8 b, f32x4 c) { return __b
 // bit-identical to running that kernel first) - the C_in-channel tensor never touches HBM and the K loop has no activation loads.
 // Every accumulator receives its products in the same order whatever MT / GX (k-step by k-step: ah*bl, al*bh, ah*bh), and the
 // activation scale is a function of the tile's ROWS only, so all geometries produce bit-identical outputs.
-template <int MT, int GX, int EP_M, bool RELU, bool ROWX, bool FIRST>
+template <int MT, int GX, int EP_M, int PF, bool RELU, bool ROWX, bool FIRST>
 __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8* __restrict__ wbase /* this channel block's fragments */, const float* __restrict__ bias,
                                         float* __restrict__ out, int C_in, int C_out, int H, int W, float w_unscale,
                                         float* __restrict__ out_amax, unsigned char* s_raw, const int* s_ex, int ex_min,
                                         int co_base, int b, int y0, int x0, const float* s_first, int C0) {
     using G = W9Geo<GX>;
-    constexpr int W9_MT = MT, NQ = G::NQ, RS = G::RS, NR = G::NR, QH = G::QH;
+    constexpr int W9_MT = MT, NQ = G::NQ, RS = G::RS, NR = G::NR;
+    constexpr int QH = G::QH;
     constexpr bool PIPE = W9_PIPE && MT == 6 && GX == 2 && !ROWX;  // the 48-channel variants have no registers for it (measured on 8 x 32: spills, 40 % slower)
     constexpr int W9_KFR = 2 * MT * 64;                       // 16-byte fragments per k-step (hi, lo)
 #if W9_PROBE & 1                      // probe build: weight buffers first, so every LDS-DMA lands 1 KiB aligned
@@ -148,18 +165,18 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     for (int q = 0; q < NQ; ++q) { k8h[q] = (f16x8)(_Float16)0; k8l[q] = (f16x8)(_Float16)0; }
 
     // fragments per stage in the packed weights: [cob][cb][3 k-steps][2][MT][64]; the third k-step exists for cb & 3 == 3 only
-    float4 pre_x[NR][4];
+    float4 pre_x[PF][NR][4];            // PF register sets: stage cb's patch sits in set cb % PF (static after the unroll by PF below)
 
-    auto prefetch_x = [&](int cb) {
+    auto prefetch_x = [&](int cb, int set) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ci = FIRST ? q : cb * W9_CB + a_c4[r] * 4 + q;            // FIRST: the spectrogram's channels, fetched once
 #if W9_PROBE & 0x80
-                pre_x[r][q] = make_float4(1.f + ci, 2.f, 3.f, 4.f);
+                pre_x[set][r][q] = make_float4(1.f + ci, 2.f, 3.f, 4.f);
 #else
-                pre_x[r][q] = (!FIRST || q < C0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_ld[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pre_x[set][r][q] = (!FIRST || q < C0) ? *reinterpret_cast<const float4*>(xb + (size_t)ci * plane + a_ld[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
             }
         }
@@ -188,9 +205,9 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         }
     };
     // split one slot's 4 pixels x 4 channels to f16 hi / lo and store them: two 8-byte stores per pixel
-    auto stage_slot = [&](int cb, int r) {
+    auto stage_slot = [&](int cb, int r, int set) {
         const float zs = a_zs[r];
-        const float* v4[4] = {&pre_x[r][0].x, &pre_x[r][1].x, &pre_x[r][2].x, &pre_x[r][3].x};
+        const float* v4[4] = {&pre_x[set][r][0].x, &pre_x[set][r][1].x, &pre_x[set][r][2].x, &pre_x[set][r][3].x};
         if (FIRST) {
             // two pixels at a time: all sixteen generated values at once cost 2 GB of scratch per launch, one pixel at a time
             // re-reads the 1x1 weights from LDS four times (measured 30 % slower)
@@ -248,17 +265,27 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
     // the ten row maxima arrive) was built and measured in round 4: bit-identical and 14 % SLOWER at C = 48 (3.62 -> 4.14 ms), 2 % at C = 96
     // (profiles/r04i): vmcnt returns in order, so the wait for the (L2-resident) maxima then also waits for the HBM-bound patch loads,
     // and the three workgroups of a CU stop overlapping their prologues with one another's K loops.
-    prefetch_w(0); prefetch_x(0);
-    for (int cb = 0; cb < ((W9_PROBE & 0x40) ? 0 : n_cb); ++cb) {
-        __syncthreads();                 // previous stage fully consumed
+    static_assert(PF == 1 || !FIRST, "the fused first conv fetches its spectrogram patch once per tile");
+    prefetch_w(0); prefetch_x(0, 0);
+    if (PF == 2) prefetch_x(1, 1);       // n_cb >= 2 (C_in % 16 == 0)
+    // In flight at the top of stage cb, oldest first: [PF 2: X(cb), issued two stages ago] W(cb) X(cb + 1).  The compiler waits for X(cb) where
+    // stage_slot reads it (counted: W and X(cb + 1) stay in flight); W(cb) is waited for in front of the stage's second barrier with the
+    // X(cb + 1) loads (4 NR instructions per lane) still out.  n_cb is even, so the loop below is unrolled by PF and the set index is static.
+    for (int cb0 = 0; cb0 < ((W9_PROBE & 0x40) ? 0 : n_cb); cb0 += PF) {
+#pragma unroll
+    for (int h = 0; h < PF; ++h) {
+        const int cb = cb0 + h;
+        if (PF == 2) w9_barrier(); else __syncthreads();      // previous stage fully consumed
         if (!(W9_PROBE & 8)) {
 #pragma unroll
             for (int r = 0; r < NR; ++r)
-                if (a_live[r]) stage_slot(cb, r);
+                if (a_live[r]) stage_slot(cb, r, h);
         }
-        __builtin_amdgcn_s_waitcnt(0);   // this stage's weight fragments have landed
-        __syncthreads();
-        if (cb + 1 < n_cb) { prefetch_w(cb + 1); if (!FIRST) prefetch_x(cb + 1); }
+        // this stage's weight fragments have landed
+        if (PF == 2) { if (cb + 1 < n_cb) w9_wait_vm<4 * NR>(); else w9_wait_vm<0>(); w9_barrier(); }
+        else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
+        if (cb + 1 < n_cb) prefetch_w(cb + 1);
+        if (!FIRST && cb + PF < n_cb) prefetch_x(cb + PF, h);
         const f16x8* s_w = (cb & 1) ? s_w1 : s_w0;
         if constexpr (PIPE) {
         // Fragment reads run AHEAD of the MFMAs that consume them (the compiler's own schedule drained lgkmcnt to 0 in front of every
@@ -397,6 +424,7 @@ __device__ __forceinline__ void w9_tile(const float* __restrict__ x, const f16x8
         }
             }
     }
+    }
     // ---- epilogue in passes of EP_M row tiles through the LDS tile [co][row][x] -> whole row segments of the tile per store
     float vmax[2] = {0.f, 0.f};          // this wave's two output rows (ty = 2 wave + q / GX)
 #if W9_PROBE & 0x20
@@ -453,6 +481,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     constexpr int W9_COB = 16 * MT, W9_KFR = 2 * MT * 64;
     // row tiles per epilogue pass: the output tile [16 EP_M][8][TW + 4] must fit the workgroup's share of the LDS (160 KB / OCC)
     constexpr int EP_M = (MT == 6) ? 3 : (GX == 3 ? 3 : 2);
+    constexpr int PF = (MT == 3 && !FIRST) ? W9_PF : 1;        // the 96-channel tile has no registers for a second set (252 of 256), the first conv no per-stage loads
     constexpr int EP_BYTES = EP_M * 16 * W9_TH * G::OUT_STRIDE * 4;
     constexpr int K_BYTES = G::PATCH_BYTES + (2 + 3) * W9_KFR * 16;
     static_assert((K_BYTES > EP_BYTES ? K_BYTES : EP_BYTES) * OCC <= 160 * 1024 - OCC * 2048, "LDS per CU");
@@ -499,9 +528,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv3x3_f16x3_w96(const float* __r
     ex_min = __builtin_amdgcn_readfirstlane(ex_min);
     ex_max = __builtin_amdgcn_readfirstlane(ex_max);
     if (ex_min != AC_EX_NONE && ex_max - ex_min > AC_ROWX_SPREAD)
-        w9_tile<MT, GX, EP_M, RELU, true, FIRST>(x, wpk + (size_t)cob * (C_in / W9_CB) * 3 * W9_KFR, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * W9_COB, b, y0, x0, s_first, C0);
+        w9_tile<MT, GX, EP_M, PF, RELU, true, FIRST>(x, wpk + (size_t)cob * (C_in / W9_CB) * 3 * W9_KFR, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * W9_COB, b, y0, x0, s_first, C0);
     else
-        w9_tile<MT, GX, EP_M, RELU, false, FIRST>(x, wpk + (size_t)cob * (C_in / W9_CB) * 3 * W9_KFR, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * W9_COB, b, y0, x0, s_first, C0);
+        w9_tile<MT, GX, EP_M, PF, RELU, false, FIRST>(x, wpk + (size_t)cob * (C_in / W9_CB) * 3 * W9_KFR, bias, out, C_in, C_out, H, W, w_unscale, out_amax, s_raw, s_ex, ex_min, cob * W9_COB, b, y0, x0, s_first, C0);
 }
 
 #ifndef AC_PROBES

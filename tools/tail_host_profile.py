@@ -24,5 +24,6 @@ pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable(); r = sp.split_track(mix, audio_dev=mix_dev); pr.disable()
 print(f"profiled run {1e3 * (time.perf_counter() - t0):.1f} ms (cProfile adds overhead)", r["timings"], "policy", r.get("timings_policy_s"))
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(top); print(s.getvalue())
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30); print(s.getvalue())
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats("audio_cut_amd", top); print(s.getvalue())
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40); print(s.getvalue())
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_callers("method 'cpu'|method 'to' of|synchronize"); print(s.getvalue()[:6000])
