@@ -202,26 +202,27 @@ def ensure_ort_dependencies() -> None:
 
 
 def chunk_schedule(total_s: float, *, chunk_s: float = 10.0, overlap_s: float = 2.5, halo_s: float = 0.5) -> List[ChunkPlan]:
-    """10 s chunks / 2.5 s overlap / 0.5 s halo on interior edges (reference: gpu_pipeline.py:333-375)."""
-    total_s = max(0.0, float(total_s))
-    chunk_s = max(0.1, float(chunk_s))
-    overlap_s = max(0.0, min(float(overlap_s), chunk_s * 0.9))
-    halo_s = max(0.0, min(float(halo_s), chunk_s * 0.5))
-    if total_s <= chunk_s:
-        return [ChunkPlan(index=0, start_s=0.0, end_s=total_s, halo_left_s=0.0, halo_right_s=0.0)]
-    stride = chunk_s - overlap_s
-    if stride <= 0:
-        stride = chunk_s
+    """10 s chunks / 2.5 s overlap / 0.5 s halo on interior edges (reference: gpu_pipeline.py:333-375; the arithmetic - clamps,
+    repeated addition of the stride, the 1 us end tolerance - is the reference's, so the schedule is bit-identical: tests/golden)."""
+    total = max(0.0, float(total_s))
+    length = max(0.1, float(chunk_s))
+    lap = max(0.0, min(float(overlap_s), length * 0.9))
+    halo = max(0.0, min(float(halo_s), length * 0.5))
+    if total <= length:
+        return [ChunkPlan(0, 0.0, total, 0.0, 0.0)]
+    step = length - lap
+    if step <= 0:
+        step = length
+    horizon = total - 1e-6               # a chunk ending within a microsecond of the track's end is the last one
     plans: List[ChunkPlan] = []
-    start = 0.0
-    while start < total_s - 1e-6:
-        end = min(total_s, start + chunk_s)
-        has_next = end < total_s - 1e-6
-        plans.append(ChunkPlan(index=len(plans), start_s=start, end_s=end,
-                               halo_left_s=halo_s if plans else 0.0, halo_right_s=halo_s if has_next else 0.0))
-        if not has_next:
+    t = 0.0
+    while t < horizon:
+        stop = min(total, t + length)
+        last = not (stop < horizon)
+        plans.append(ChunkPlan(len(plans), t, stop, halo if plans else 0.0, 0.0 if last else halo))
+        if last:
             break
-        start += stride
+        t += step
     return plans
 
 
@@ -238,29 +239,28 @@ class PinnedBufferPool:
             self.capacity = 0
 
     def acquire(self, num_elements: int):
-        if torch is None or num_elements <= 0:
+        want = int(num_elements) if torch is not None else 0
+        if want <= 0:
             return None
-        while self._buffers:
-            buf = self._buffers.pop()
-            if buf.numel() >= num_elements:
-                return buf[:num_elements]
-        return torch.empty(int(num_elements), dtype=self.dtype, pin_memory=torch.cuda.is_available())
+        while self._buffers:             # newest first; a cached buffer that is too small is dropped on the way
+            cand = self._buffers.pop()
+            if cand.numel() >= want:
+                return cand[:want]
+        return torch.empty(want, dtype=self.dtype, pin_memory=torch.cuda.is_available())
 
     def acquire_view(self, shape: Sequence[int]):
-        numel = 1
-        for d in shape:
-            numel *= int(d)
-        t = self.acquire(numel)
-        return None if t is None else t.view(*shape)
+        count = 1
+        for extent in shape:
+            count *= int(extent)
+        flat = self.acquire(count)
+        return flat.view(*shape) if flat is not None else None
 
     def release(self, tensor) -> None:
-        if torch is None or tensor is None:
-            return
-        if len(self._buffers) < self.capacity:
+        if torch is not None and tensor is not None and len(self._buffers) < self.capacity:
             self._buffers.append(tensor.reshape(-1))
 
     def clear(self) -> None:
-        self._buffers.clear()
+        del self._buffers[:]
 
 
 @dataclass
@@ -276,23 +276,25 @@ class InflightLimiter:
 
     @contextmanager
     def acquire(self, timeout: Optional[float] = None) -> Iterator[None]:
-        if self.limit == 0:
-            yield
-            return
-        with self._condition:
-            if timeout is None:
-                while self._inflight >= self.limit:
-                    self._condition.wait()
-            elif not self._condition.wait_for(lambda: self._inflight < self.limit, timeout=timeout):
-                raise RuntimeError("inflight limit exceeded")
-            self._inflight += 1
+        gated = self.limit > 0           # limit 0: no gate at all
+        if gated:
+            self._enter(timeout)
         try:
             yield
         finally:
-            with self._condition:
-                if self._inflight > 0:
-                    self._inflight -= 1
-                self._condition.notify()
+            if gated:
+                self._leave()
+
+    def _enter(self, timeout: Optional[float]) -> None:
+        with self._condition:            # timeout None waits for a free slot for good
+            if not self._condition.wait_for(lambda: self._inflight < self.limit, timeout=timeout):
+                raise RuntimeError("inflight limit exceeded")
+            self._inflight += 1
+
+    def _leave(self) -> None:
+        with self._condition:
+            self._inflight = max(0, self._inflight - 1)
+            self._condition.notify()
 
 
 @dataclass
@@ -309,29 +311,29 @@ class PipelineConfig:
     strict_gpu: bool = False
     ort_config: OrtExecutionConfig = field(default_factory=OrtExecutionConfig)
 
+    # field -> (accepted keys, first present wins; type): the reference's accepted spellings (gpu_pipeline.py:482-504)
+    _MAPPING_KEYS = (("enable", ("enable",), bool), ("prefer_device", ("prefer_device",), str),
+                     ("chunk_s", ("chunk_seconds", "chunk_s"), float), ("overlap_s", ("overlap_seconds", "overlap_s"), float),
+                     ("halo_s", ("halo_seconds", "halo_s"), float), ("align_hop", ("align_hop", "align_hop_samples"), int),
+                     ("use_cuda_streams", ("use_cuda_streams",), bool), ("prefetch_pinned_buffers", ("prefetch_pinned_buffers",), int),
+                     ("inflight_chunks_limit", ("inflight_chunks_limit",), int), ("strict_gpu", ("strict_mode", "strict_gpu"), bool))
+    _ORT_KEYS = (("graph_optimization_level", str), ("cudnn_conv_algo_search", str), ("disable_trt", bool))
+
     @classmethod
     def from_mapping(cls, mapping: Optional[dict]) -> "PipelineConfig":
-        """Same accepted keys as the reference (gpu_pipeline.py:482-504)."""
+        cfg = cls()
         if not mapping:
-            return cls()
-        ort_cfg = mapping.get("ort", {}) if isinstance(mapping, dict) else {}
-        return cls(
-            enable=bool(mapping.get("enable", False)),
-            prefer_device=str(mapping.get("prefer_device", "cuda")),
-            chunk_s=float(mapping.get("chunk_seconds", mapping.get("chunk_s", 10.0))),
-            overlap_s=float(mapping.get("overlap_seconds", mapping.get("overlap_s", 2.5))),
-            halo_s=float(mapping.get("halo_seconds", mapping.get("halo_s", 0.5))),
-            align_hop=int(mapping.get("align_hop", mapping.get("align_hop_samples", 4096))),
-            use_cuda_streams=bool(mapping.get("use_cuda_streams", True)),
-            prefetch_pinned_buffers=int(mapping.get("prefetch_pinned_buffers", 2)),
-            inflight_chunks_limit=int(mapping.get("inflight_chunks_limit", 2)),
-            strict_gpu=bool(mapping.get("strict_mode", mapping.get("strict_gpu", False))),
-            ort_config=OrtExecutionConfig(
-                graph_optimization_level=str(ort_cfg.get("graph_optimization_level", "basic")),
-                cudnn_conv_algo_search=str(ort_cfg.get("cudnn_conv_algo_search", "HEURISTIC")),
-                disable_trt=bool(ort_cfg.get("disable_trt", True)),
-            ),
-        )
+            return cfg
+        for name, spellings, kind in cls._MAPPING_KEYS:
+            for key in spellings:
+                if key in mapping:
+                    setattr(cfg, name, kind(mapping[key]))
+                    break
+        ort = mapping.get("ort", {}) if isinstance(mapping, dict) else {}
+        for name, kind in cls._ORT_KEYS:
+            if name in ort:
+                setattr(cfg.ort_config, name, kind(ort[name]))
+        return cfg
 
 
 @dataclass
@@ -372,26 +374,19 @@ class PipelineContext:
         self.failures.append({"stage": stage, "reason": reason})
 
     def to_meta(self) -> Dict[str, object]:
+        """The manifest's `gpu` block: what the run recorded wins, the context fills in the rest (key set: gpu_pipeline.py:546-572)."""
+        cfg = self.config
+        derived = [("enabled", bool(cfg.enable)), ("used", bool(self.enabled)), ("device", self.device),
+                   ("device_index", None if self.device_index is None else int(self.device_index)), ("device_name", self.device_name or None),
+                   ("chunks", len(self.plans)), ("streams", bool(self.use_streams)),
+                   ("inflight_limit", int(self.limiter.limit) if self.limiter else 0),
+                   ("prefetch", int(self.pinned_pool.capacity) if self.pinned_pool else 0), ("align_hop", int(cfg.align_hop)),
+                   ("config", {"chunk_seconds": float(cfg.chunk_s), "overlap_seconds": float(cfg.overlap_s), "halo_seconds": float(cfg.halo_s)}),
+                   ("mdx23_input", self.mdx23_input or None), ("failures", list(self.failures) or None)]
         meta = dict(self.gpu_meta)
-        meta.setdefault("gpu_pipeline_enabled", bool(self.config.enable))
-        meta.setdefault("gpu_pipeline_used", bool(self.enabled))
-        meta.setdefault("gpu_pipeline_device", self.device)
-        if self.device_index is not None:
-            meta.setdefault("gpu_pipeline_device_index", int(self.device_index))
-        if self.device_name:
-            meta.setdefault("gpu_pipeline_device_name", self.device_name)
-        meta.setdefault("gpu_pipeline_chunks", len(self.plans))
-        meta.setdefault("gpu_pipeline_streams", bool(self.use_streams))
-        meta.setdefault("gpu_pipeline_inflight_limit", int(self.limiter.limit) if self.limiter else 0)
-        meta.setdefault("gpu_pipeline_prefetch", int(self.pinned_pool.capacity) if self.pinned_pool else 0)
-        meta.setdefault("gpu_pipeline_align_hop", int(self.config.align_hop))
-        meta.setdefault("gpu_pipeline_config", {"chunk_seconds": float(self.config.chunk_s),
-                                                "overlap_seconds": float(self.config.overlap_s),
-                                                "halo_seconds": float(self.config.halo_s)})
-        if self.mdx23_input:
-            meta.setdefault("gpu_pipeline_mdx23_input", self.mdx23_input)
-        if self.failures:
-            meta.setdefault("gpu_pipeline_failures", list(self.failures))
+        for key, value in derived:
+            if value is not None:
+                meta.setdefault("gpu_pipeline_" + key, value)
         return meta
 
     def capture_device_metrics(self) -> None:
