@@ -89,7 +89,7 @@ def items_per_chunk(chunk_len: int, align_hop: int) -> int:
 class MDX23HipBackend(IVocalSeparatorBackend):
     def __init__(self, model_dir: Optional[Path] = None, *, device: str = "cuda:0", align_hop: Optional[int] = None,
                  weights: Optional[Dict[str, np.ndarray]] = None, spec: TfcTdfSpec = TfcTdfSpec(), seed: int = 0,
-                 max_items_per_forward: int = 16, ctx: Optional["_native.Context"] = None) -> None:
+                 max_items_per_forward: int = 64, ctx: Optional["_native.Context"] = None) -> None:
         self._model_dir = Path(model_dir) if model_dir else None
         self._device = device
         self._align_hop = int(align_hop if align_hop is not None else os.getenv("MDX23_ALIGN_HOP", 4096))
@@ -99,6 +99,8 @@ class MDX23HipBackend(IVocalSeparatorBackend):
         self._sr = 44100
         self._net: Optional[TfcTdfNet] = None
         self._ctx = ctx
+        # items (3 s U-Net windows) per forward: 64 = a whole 4-min track in one forward, 42 GB of activations of the 288 GB; measured 1.2 % faster
+        # than two forwards of 32 on the same box (the deep levels' grids fill the chip better), bit-identical per item (profiles/r04ab)
         self.max_items_per_forward = int(max_items_per_forward)
         pref = str(get_config("enhanced_separation.mdx23.output_type", "auto")).strip().lower() or "auto"
         self._output_type_pref = pref if pref in {"auto", "vocal", "instrumental"} else "auto"

@@ -291,7 +291,7 @@ def main() -> None:
                     help="c2: 4-min tracks, K per rank (default; N > 1 deals the C3 seeds); c3: exactly the 32 C3 tracks over the ranks; "
                          "c4: the c2 tracks in vpbd_acoustic mode with the Silero network as the chunked VAD; c5: 30-min tracks")
     ap.add_argument("--track-seconds", type=float, default=None, help="default 240 (c2 / c3) or 1800 (c5)")
-    ap.add_argument("--items-per-forward", type=int, default=32)
+    ap.add_argument("--items-per-forward", type=int, default=64)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=240.0,
                     help="length of the C2 track's prefix the CPU oracle is timed on (default: the whole 240 s track, about 170 s of CPU "
                          "on 16 threads); 0 disables the CPU baseline leg")
