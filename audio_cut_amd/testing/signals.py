@@ -139,15 +139,26 @@ def c5_long_form(duration_s: float = 1800.0, seed: int = 5, sr: int = SR, sectio
     each section with its own level so no two minutes are alike.  `sr=48000, stereo=True` gives the 48 kHz stereo source the
     loader leg resamples; `sr=44100` (mono channel mean) is the post-resample parity input."""
     n = int(round(duration_s * sr))
-    parts = []
-    i = 0
-    got = 0
+
+    def section(i: int, length: float) -> np.ndarray:
+        return c2_song(length, seed=seed * 1000 + i, sr=sr, stereo=stereo) * np.float32(0.55 + 0.45 * ((i * 7) % 10) / 9.0)
+
+    # the sections are independent: plan them first (a section of `length` seconds is round(length * sr) samples), then generate eight at
+    # a time on a thread pool (the generator is numpy-bound); a plan that the generator does not confirm falls back to the serial loop
+    plan, got = [], 0
     while got < n:
         length = min(section_s, (n - got) / float(sr))
-        sec = c2_song(length, seed=seed * 1000 + i, sr=sr, stereo=stereo)
-        sec = sec * np.float32(0.55 + 0.45 * ((i * 7) % 10) / 9.0)
-        parts.append(sec)
-        got += sec.shape[-1]
-        i += 1
+        plan.append(length)
+        got += int(round(length * sr))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as pool:
+        parts = list(pool.map(lambda it: section(*it), enumerate(plan)))
+    if any(p.shape[-1] != int(round(length * sr)) for p, length in zip(parts, plan)):
+        parts, i, got = [], 0, 0
+        while got < n:
+            sec = section(i, min(section_s, (n - got) / float(sr)))
+            parts.append(sec)
+            got += sec.shape[-1]
+            i += 1
     out = np.concatenate(parts, axis=-1)[..., :n]
     return np.ascontiguousarray(out, dtype=np.float32)
