@@ -291,7 +291,10 @@ def main() -> None:
                     help="c2: 4-min tracks, K per rank (default; N > 1 deals the C3 seeds); c3: exactly the 32 C3 tracks over the ranks; "
                          "c4: the c2 tracks in vpbd_acoustic mode with the Silero network as the chunked VAD; c5: 30-min tracks")
     ap.add_argument("--track-seconds", type=float, default=None, help="default 240 (c2 / c3) or 1800 (c5)")
-    ap.add_argument("--items-per-forward", type=int, default=64)
+    ap.add_argument("--items-per-forward", type=int, default=None,
+                    help="U-Net windows per forward; default 64 (a 4-min track in one forward: -1.2 %% per track), 32 for --config c4: with two "
+                         "tracks in flight the long VPBD / Silero tail of one track runs beside the other's U-Net, and behind 2x longer launches "
+                         "its small kernels wait longer (profiles/r04ak)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=240.0,
                     help="length of the C2 track's prefix the CPU oracle is timed on (default: the whole 240 s track, about 170 s of CPU "
                          "on 16 threads); 0 disables the CPU baseline leg")
@@ -305,6 +308,8 @@ def main() -> None:
     ap.add_argument("--write-golden", default=None, metavar="PATH",
                     help="(c3, N = 1) write the per-track SHA-1 table of this run to PATH (committed as tests/golden/c3_n1_sha1.json)")
     args = ap.parse_args()
+    if args.items_per_forward is None:
+        args.items_per_forward = 32 if args.config == "c4" else 64
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(_launch_ranks(args.gpus, sys.argv[1:]))
