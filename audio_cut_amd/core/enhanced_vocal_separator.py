@@ -238,22 +238,17 @@ class EnhancedVocalSeparator:
                 if ee > es:
                     feature_builder.add_chunk_range(plan, cs, ce)
             cache = feature_builder.finalize(audio)
-        vocal_h = torch.empty(sep.vocal.shape, dtype=torch.float32, pin_memory=True)
-        inst_h = torch.empty(sep.instrumental.shape, dtype=torch.float32, pin_memory=True)
-
-        def download_stems():
-            # The stem downloads (pinned host memory, side stream) are blit KERNELS on this runtime (__amd_rocclr_copyBuffer, 0.78 ms per stem at
-            # PCIe speed) and a kernel that shares the chip with one runs ten times longer (track tail trace, profiles/r04f: k_sum_squares 0.48 ms,
-            # the VAD's k_frame_rms 0.82 ms beside them).  So they start only when the VAD's kernels have come back - the host then has 2-3 ms
-            # of window bookkeeping to do, which hides them - instead of the moment the separation is done.
-            with torch.cuda.stream(side):
-                side.wait_event(sep_done)
-                sep.vocal.record_stream(side); sep.instrumental.record_stream(side)
-                vocal_h.copy_(sep.vocal, non_blocking=True)
-                inst_h.copy_(sep.instrumental, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-            return ev
+            # the stem downloads (pinned host memory) follow on the same side stream as soon as the separation is done,
+            # beside the VAD / marker / detector kernels of the main stream
+            t1 = time.perf_counter()
+            side.wait_event(sep_done)
+            sep.vocal.record_stream(side); sep.instrumental.record_stream(side)
+            vocal_h = torch.empty(sep.vocal.shape, dtype=torch.float32, pin_memory=True)
+            inst_h = torch.empty(sep.instrumental.shape, dtype=torch.float32, pin_memory=True)
+            vocal_h.copy_(sep.vocal, non_blocking=True)
+            inst_h.copy_(sep.instrumental, non_blocking=True)
+            stems_on_host = torch.cuda.Event()
+            stems_on_host.record()
 
         gpu_context.capture_device_metrics()      # an SMI query costs the host ~1 ms: taken here, while it waits for the U-Net anyway (and the GPU is under load)
 
@@ -266,14 +261,10 @@ class EnhancedVocalSeparator:
                                    focus_pad_s=float(get_config("advanced_vad.focus_window_pad_s", 0.2)), inference_fn=vad_fn)
         if hasattr(vad_fn, "precompute"):         # every chunk's windows in one batch of launches and one download
             pre = vad_fn.precompute(sep.chunk_vocal, sep.chunk_offsets, [ce - cs for cs, ce, _, _ in sep.chunk_ranges])
-            t1 = time.perf_counter()
-            stems_on_host = download_stems()
             for plan, chunk in zip(live_plans, pre):
                 chunk_vad.process_chunk(plan, chunk, sr)
         else:                                     # injected VadFn contract: host float32 chunks
             host = sep.chunk_vocal.cpu().numpy()
-            t1 = time.perf_counter()
-            stems_on_host = download_stems()
             for plan, off, (cs, ce, es, ee) in zip(live_plans, sep.chunk_offsets, sep.chunk_ranges):
                 chunk_vad.process_chunk(plan, host[off: off + (ce - cs)], sr)
         vad_segments = chunk_vad.finalize()
