@@ -39,7 +39,7 @@ def load() -> C.CDLL:
                           f"(there is no CPU fallback for the HIP path)")
     lib = C.CDLL(str(path))
     _declare(lib)
-    if lib.ac_abi_version() != 5:
+    if lib.ac_abi_version() != 6:
         raise NativeError("libaudiocut_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -73,6 +73,7 @@ SIGNATURES = {
     "ac_mdx_assemble_ola": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "ac_mdx_chunk_vocal": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P]),
     "ac_sum_squares": (C.c_int, [_P, _P, _I64, _P, _I, _P]),
+    "ac_window_sum_squares": (C.c_int, [_P, _P, _I64, _P, _P, _I, _P, _P]),
     "ac_conv3x3_f16x3": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_w96": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "ac_conv3x3_f16x3_s8": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
@@ -822,6 +823,27 @@ class Context:
         buf = torch.empty(parts, dtype=torch.float64, device=self.device)
         _check(self.lib.ac_sum_squares(self._h, _ptr(x), n, _ptr(buf), parts, _stream()))
         return buf
+
+    WINDOW_MEAN_SQUARE_MAX = 8191          # longest window `window_mean_squares` takes: below 8192 samples `mean_square` sums ONE partial
+
+    def window_mean_squares(self, x: torch.Tensor, starts, ends) -> np.ndarray:
+        """`[mean_square(x[a:b]) for a, b in zip(starts, ends)]` in one launch and one download, bit-identical to the per-window calls
+        (0.0 for an empty window).  Every window must be at most WINDOW_MEAN_SQUARE_MAX samples long."""
+        self._chk_f32(x)
+        a = np.asarray(starts, dtype=np.int64); b = np.asarray(ends, dtype=np.int64)
+        n = int(x.numel())
+        if a.shape != b.shape or a.ndim != 1:
+            raise ValueError("starts / ends must be equally long 1-D sequences")
+        if a.size == 0:
+            return np.zeros(0, dtype=np.float64)
+        if np.any(a < 0) or np.any(b > n) or np.any(b < a) or np.any(b - a > self.WINDOW_MEAN_SQUARE_MAX):
+            raise ValueError("windows must lie inside the wave and be at most WINDOW_MEAN_SQUARE_MAX samples long")
+        out = torch.empty(a.size, dtype=torch.float64, device=self.device)
+        a_dev, b_dev = self.to_device(a), self.to_device(b)       # named: a temporary would hand its block back to the allocator before the launch
+        _check(self.lib.ac_window_sum_squares(self._h, _ptr(x), n, _ptr(a_dev), _ptr(b_dev), int(a.size), _ptr(out), _stream()))
+        sums = out.cpu().numpy()
+        length = (b - a).astype(np.float64)
+        return np.where(length > 0, sums / np.where(length > 0, length, 1.0), 0.0)
 
     def mean_square(self, x: torch.Tensor) -> float:
         self._chk_f32(x)

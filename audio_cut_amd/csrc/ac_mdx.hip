@@ -313,6 +313,29 @@ __global__ __launch_bounds__(256) void k_sum_squares(const float* __restrict__ x
     if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
+// The same sum for MANY short windows of one wave in one launch (the VPBD beat candidates' vocal-risk windows, beat_candidates.py:97-109: one
+// `mean_square(vocal[a:b])` - a launch and a download - per candidate until ABI 6).  One workgroup per window, summed EXACTLY as k_sum_squares sums a
+// slice with one partial (thread t adds x[a + t], x[a + t + 256], ... in float64, then the same block reduction), so out[w] is bit-identical to
+// ac_sum_squares(x + a, b - a, &partial, 1): windows must be shorter than 8192 samples, where the host wrapper asks for exactly one partial.
+__global__ __launch_bounds__(256) void k_window_sum_squares(const float* __restrict__ x, const int64_t* __restrict__ w_start,
+                                                            const int64_t* __restrict__ w_end, double* __restrict__ out) {
+    __shared__ double s_red[4];
+    const int64_t a = w_start[blockIdx.x], b = w_end[blockIdx.x];
+    double acc = 0.0;
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) { const double v = x[i]; acc += v * v; }
+    const double tot = block_sum_f64_256(acc, s_red);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+extern "C" int ac_window_sum_squares(ac_ctx* ctx, const float* x, int64_t n, const int64_t* w_start, const int64_t* w_end, int n_windows,
+                                     double* out, void* stream) {
+    AC_REQUIRE(ctx && x && w_start && w_end && out, "null pointer");
+    AC_REQUIRE(n > 0 && n_windows > 0, "sizes must be positive");      // window bounds live on the device: the caller keeps 0 <= start <= end <= n, end - start < 8192
+    hipLaunchKernelGGL(k_window_sum_squares, dim3((unsigned)n_windows), dim3(256), 0, (hipStream_t)stream, x, w_start, w_end, out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
 extern "C" int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int n_partials, void* stream) {
     AC_REQUIRE(ctx && x && partials, "null pointer");
     AC_REQUIRE(n > 0 && n_partials > 0 && n_partials <= 4096, "n_partials must be in [1, 4096]");

@@ -96,11 +96,14 @@ class _VocalRisk:
         else:
             self.peak = float(np.max(np.abs(self.mono)))
 
+    def _window(self, t: float):
+        c = int(round(float(t) * self.sr))
+        return max(0, c - self.half), min(self.n, c + self.half)
+
     def __call__(self, t: float) -> float:
         if self.mono is None or self.peak <= 1e-9:
             return 0.0
-        c = int(round(float(t) * self.sr))
-        a, b = max(0, c - self.half), min(self.n, c + self.half)
+        a, b = self._window(t)
         if a >= b:
             return 0.0
         if self.dev is not None and self.hip is not None:
@@ -108,6 +111,22 @@ class _VocalRisk:
         else:
             ms = float(np.mean(np.square(self.mono[a:b], dtype=np.float64)))
         return max(0.0, min(1.0, float(np.sqrt(ms)) / self.peak))
+
+    def many(self, times) -> List[float]:
+        """`[self(t) for t in times]`; on the device every window's sum of squares comes from ONE launch and one download
+        (`ac_window_sum_squares`, bit-identical to the per-window `mean_square`) instead of a host round trip per candidate."""
+        times = list(times)
+        if (self.mono is None or self.peak <= 1e-9 or self.dev is None or self.hip is None or not times
+                or 2 * self.half > self.hip.WINDOW_MEAN_SQUARE_MAX):
+            return [self(t) for t in times]
+        spans = [self._window(t) for t in times]
+        live = [i for i, (a, b) in enumerate(spans) if a < b]
+        out = [0.0] * len(times)
+        if live:
+            ms = self.hip.window_mean_squares(self.dev, [spans[i][0] for i in live], [spans[i][1] for i in live])
+            for i, v in zip(live, ms):
+                out[i] = max(0.0, min(1.0, float(np.sqrt(float(v))) / self.peak))
+        return out
 
 
 def generate_beat_candidates(*, beat_times: Iterable[float], rms_series: Iterable[float], hop_s: float, duration_s: float,
@@ -131,7 +150,7 @@ def generate_beat_candidates(*, beat_times: Iterable[float], rms_series: Iterabl
         return []
     risk = _VocalRisk(vocal_track, sample_rate, guard_win_ms, hip=hip, vocal_dev=vocal_dev)
     every = max(1, int(bars_per_cut))
-    out: List[CutCandidate] = []
+    picked = []                          # (time, bar) of every candidate first: their vocal-risk windows are measured together
     for group in _runs_of_consecutive(sorted(high)):
         for k, bar in enumerate(group):
             if k % every != 0 or bar >= len(bars) - 1:
@@ -139,9 +158,11 @@ def generate_beat_candidates(*, beat_times: Iterable[float], rms_series: Iterabl
             t = float(bars[bar])
             if t <= 0.0 or t >= duration_s:
                 continue
-            out.append(CutCandidate(t=t, score=float(base_score), source=CandidateSource.BEAT, reasons=["high_energy_beat"],
-                                    features={"vocal_cut_risk": risk(t)}, meta={"bar_index": int(bar), "bars_per_cut": int(bars_per_cut)}))
-    return out
+            picked.append((t, bar))
+    risks = risk.many([t for t, _ in picked])
+    return [CutCandidate(t=t, score=float(base_score), source=CandidateSource.BEAT, reasons=["high_energy_beat"],
+                         features={"vocal_cut_risk": r}, meta={"bar_index": int(bar), "bars_per_cut": int(bars_per_cut)})
+            for (t, bar), r in zip(picked, risks)]
 
 
 __all__ = ["generate_beat_candidates", "detect_chorus_regions"]

@@ -29,7 +29,7 @@ extern "C" {
 #define AC_E_HIP (-2)       /* a HIP runtime call failed */
 #define AC_E_NOMEM (-3)
 
-#define AC_ABI_VERSION 5        /* 5: + ac_frame_rms_multi */
+#define AC_ABI_VERSION 6        /* 5: + ac_frame_rms_multi; 6: + ac_window_sum_squares */
 
 typedef struct ac_ctx ac_ctx;
 
@@ -168,6 +168,12 @@ int ac_mdx_chunk_vocal(ac_ctx* ctx, const float* wave, const int64_t* chunk_len,
 
 /* enhanced_vocal_separator.py:490-501: float64 partial sums of x^2 (n_partials blocks, summed by the host). */
 int ac_sum_squares(ac_ctx* ctx, const float* x, int64_t n, double* partials, int n_partials, void* stream);
+
+/* src/audio_cut/cutting/beat_candidates.py:97-109 (`_VocalRisk`: sqrt(mean(vocal[c - w : c + w]^2)) / peak per beat candidate): the float64 sums
+ * of x^2 over n_windows windows [w_start[i], w_end[i]) (device arrays; every window shorter than 8192 samples) in ONE launch; out[i] is
+ * bit-identical to ac_sum_squares over that slice with one partial. */
+int ac_window_sum_squares(ac_ctx* ctx, const float* x, int64_t n, const int64_t* w_start, const int64_t* w_end, int n_windows,
+                          double* out, void* stream);
 
 /* ---- U-Net layers (MFMA kernels; no MIOpen / rocBLAS path) ----------------------------------- */
 

@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
         assert name in _native.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_native.SIGNATURES) == set(names)
-    assert lib.ac_abi_version() == 5
+    assert lib.ac_abi_version() == 6
 
 
 def test_size_helpers_need_no_gpu(lib):

@@ -296,3 +296,29 @@ def test_kernels_stay_exact_beside_the_conv_on_another_stream(hip_ctx):
     print("launches beside the conv (wrong / total):", {k: f"{wrong[k]} / {count[k]}" for k in victims})
     assert all(v == 0 for v in wrong.values()), wrong
     assert min(count.values()) >= 20
+
+
+@pytest.mark.gpu
+def test_window_mean_squares_is_the_per_window_mean_square_bit_for_bit(hip_ctx):
+    """ABI 6 (`ac_window_sum_squares`): the VPBD beat candidates' vocal-risk windows (`beat_candidates.py:97-109`) in one launch - every value
+    bit-identical to `mean_square` of the slice (the per-candidate launch + download it replaces), empty and clipped windows included; and
+    `_VocalRisk.many` == the per-candidate calls on a track."""
+    from audio_cut_amd.cutting.beat_candidates import _VocalRisk
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(3 * SR) * np.exp(rng.uniform(-9, 0, 3 * SR))).astype(np.float32)
+    dev = hip_ctx.to_device(x)
+    n = len(x)
+    starts = np.concatenate([rng.integers(0, n - 8191, 200), [0, n - 5, n - 8191, 17, n]])
+    lens = np.concatenate([rng.integers(1, 8192, 200), [8191, 5, 8191, 0, 0]])
+    ends = np.minimum(starts + lens, n)
+    got = hip_ctx.window_mean_squares(dev, starts, ends)
+    want = np.array([hip_ctx.mean_square(dev[a:b]) if b > a else 0.0 for a, b in zip(starts, ends)])
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    assert np.allclose(got, [np.mean(np.square(x[a:b], dtype=np.float64)) if b > a else 0.0 for a, b in zip(starts, ends)], rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        hip_ctx.window_mean_squares(dev, [0], [8192])
+    risk = _VocalRisk(x, SR, 80.0, hip=hip_ctx, vocal_dev=dev)
+    times = list(rng.uniform(-0.05, 3.05, 60)) + [0.0, 3.0]
+    assert risk.many(times) == [risk(t) for t in times]
+    host = _VocalRisk(x, SR, 80.0)
+    assert host.many(times) == [host(t) for t in times]
